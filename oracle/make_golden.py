@@ -1,0 +1,429 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REFERENCE's own code.  Build container only.
+
+TEST INFRASTRUCTURE — NOT PRODUCT.  Reads /root/reference (never copied, never shipped):
+  * training/patch_text_aggregation.py is imported (stub modules registered for the four
+    packages that are absent offline: ultralytics, faiss, gensim, torchvision) and its
+    `CrossModalAttention`, `PatchTextAggregation.aggregation` / `.compute_global_embedding_batch`
+    and `CLIPTextTokenizer.get_embeddings` / `CLIPPatchTokenizer.encode_weighted_bounding_boxes`
+    run as written, on shell instances (no `from_pretrained` — nothing is fetched).
+  * `compute_contrastive_loss` / `cosine_distillation_loss` are lifted by `ast` from
+    training/CLIP_image_distillation.py (importing that module would fetch models at import time).
+  * the towers are HF transformers `CLIPModel(CLIPConfig(...))` built from a local config and loaded
+    with `dclip_amd.synth.synth_clip_state_dict` weights (eager attention, fp32 and fp64).
+
+Every array written is data (inputs / expected outputs); weights are re-derived from seeds by
+`dclip_amd.synth` and only their checksums are stored.  Versions are recorded in each file.
+
+Usage:  python oracle/make_golden.py            (writes tests/golden/)
+"""
+from __future__ import annotations
+
+import ast
+import os
+import sys
+import tempfile
+import types
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+import transformers
+from transformers import CLIPConfig, CLIPModel
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+OUT = os.path.join(REPO, "tests", "golden")
+sys.path.insert(0, REPO)
+
+from dclip_amd import config as dcfg  # noqa: E402
+from dclip_amd import synth  # noqa: E402
+from dclip_amd.probe import probe_vector  # noqa: E402
+
+torch.set_num_threads(8)
+VERSIONS = f"torch {torch.__version__}; transformers {transformers.__version__}; numpy {np.__version__}"
+
+
+# ----------------------------------------------------------------------------- reference access
+
+def import_reference_teacher():
+    for name, attrs in (("ultralytics", {"YOLO": object}), ("faiss", {}), ("gensim", {}),
+                        ("gensim.downloader", {}), ("torchvision", {}), ("torchvision.transforms", {})):
+        if name not in sys.modules:
+            m = types.ModuleType(name)
+            for k, v in attrs.items():
+                setattr(m, k, v)
+            sys.modules[name] = m
+    sys.modules["gensim"].downloader = sys.modules["gensim.downloader"]
+    sys.modules["torchvision"].transforms = sys.modules["torchvision.transforms"]
+    sys.path.insert(0, os.path.join(REF, "training"))
+    import patch_text_aggregation as pta  # noqa
+    import text_tokenizer as tt  # noqa
+    import image_tokenizer as it  # noqa
+    return pta, tt, it
+
+
+def lift_losses():
+    """Function bodies only; the module's top level (which instantiates tokenizers) never runs."""
+    src = open(os.path.join(REF, "training", "CLIP_image_distillation.py")).read()
+    tree = ast.parse(src)
+    fns = {}
+    for node in ast.walk(tree):
+        if isinstance(node, ast.ClassDef) and node.name == "CLIPImageDistillation":
+            for item in node.body:
+                if isinstance(item, ast.FunctionDef) and item.name in ("compute_contrastive_loss",
+                                                                       "cosine_distillation_loss"):
+                    mod = ast.Module(body=[item], type_ignores=[])
+                    ns = {"torch": torch, "F": F}
+                    exec(compile(mod, "<lifted>", "exec"), ns)
+                    fns[item.name] = ns[item.name]
+    shell = types.SimpleNamespace(device="cpu")
+    return (lambda i, t, temperature=0.05: fns["compute_contrastive_loss"](shell, i, t, temperature),
+            lambda s, t: fns["cosine_distillation_loss"](shell, s, t))
+
+
+def hf_config(cfg: dcfg.ClipConfig) -> CLIPConfig:
+    v, t = cfg.vision, cfg.text
+    c = CLIPConfig(
+        vision_config=dict(hidden_size=v.hidden_size, intermediate_size=v.intermediate_size,
+                           num_hidden_layers=v.num_hidden_layers, num_attention_heads=v.num_attention_heads,
+                           image_size=v.image_size, patch_size=v.patch_size, layer_norm_eps=v.layer_norm_eps,
+                           projection_dim=cfg.projection_dim),
+        text_config=dict(hidden_size=t.hidden_size, intermediate_size=t.intermediate_size,
+                         num_hidden_layers=t.num_hidden_layers, num_attention_heads=t.num_attention_heads,
+                         max_position_embeddings=t.max_position_embeddings, vocab_size=t.vocab_size,
+                         bos_token_id=t.bos_token_id, eos_token_id=t.eos_token_id, pad_token_id=t.eos_token_id,
+                         layer_norm_eps=t.layer_norm_eps, projection_dim=cfg.projection_dim),
+        projection_dim=cfg.projection_dim)
+    c._attn_implementation = "eager"
+    return c
+
+
+def hf_model(cfg: dcfg.ClipConfig, sd, dtype=torch.float32) -> CLIPModel:
+    m = CLIPModel(hf_config(cfg))
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    missing = [k for k in missing if "position_ids" not in k]
+    assert not missing and not unexpected, (missing, unexpected)
+    return m.to(dtype).eval()
+
+
+class TensorReturning(nn.Module):
+    """4.x call semantics the reference assumes (`.float()` on the result,
+    training/CLIP_image_distillation.py:601,:616): hf 5.x returns a ModelOutput — read .pooler_output."""
+
+    def __init__(self, m):
+        super().__init__()
+        self.m = m
+        self.text_model = m.text_model
+        self.text_projection = m.text_projection
+
+    def get_image_features(self, pixel_values=None, **kw):
+        return self.m.get_image_features(pixel_values=pixel_values).pooler_output
+
+    def get_text_features(self, input_ids=None, attention_mask=None, **kw):
+        return self.m.get_text_features(input_ids=input_ids).pooler_output
+
+    def parameters(self, recurse=True):
+        return self.m.parameters(recurse)
+
+
+def save(name, **arrays):
+    os.makedirs(OUT, exist_ok=True)
+    arrays["__versions__"] = np.array(VERSIONS)
+    conv = {}
+    for k, v in arrays.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        conv[k] = v
+    path = os.path.join(OUT, name)
+    np.savez_compressed(path, **conv)
+    print(f"wrote {path}  ({os.path.getsize(path) / 1024:.1f} KiB, {len(conv)} arrays)")
+
+
+def grad_probes(named_grads):
+    """Per-tensor (norm, <g, probe>) — the probe vector is re-derivable from the tensor's key."""
+    out = {}
+    for k, g in named_grads.items():
+        g = g.detach().double().reshape(-1)
+        out[k] = np.array([float(g.norm()), float(g @ probe_vector(k, g.numel()).double())])
+    return out
+
+
+# ----------------------------------------------------------------------------- F1 losses
+
+def gen_losses(ref_con, ref_cos):
+    arrs = {}
+    g = torch.Generator().manual_seed(1234)
+    img, txt, tea = (torch.randn(8, 512, generator=g) for _ in range(3))
+    arrs["survey_con"] = ref_con(img, txt)          # SURVEY.md §8c quotes 2.1221024990081787
+    arrs["survey_cos"] = ref_cos(img, tea)          # and 1.0040297508239746
+    cases = [("b1_p512", 1, 512, 11), ("b2_p512", 2, 512, 12), ("b8_p512", 8, 512, 13), ("b8_p64", 8, 64, 14),
+             ("b37_p768", 37, 768, 15), ("b256_p512", 256, 512, 16), ("b1024_p512", 1024, 512, 17)]
+    for name, B, P, seed in cases:
+        gi = torch.Generator().manual_seed(seed)
+        i = torch.randn(B, P, generator=gi) * 1.7
+        t = torch.randn(B, P, generator=gi) + 0.1 * i            # weakly correlated: loss ~ 2-3, grads O(1e-3)
+        e = torch.randn(B, P, generator=gi)
+        i.requires_grad_(True), t.requires_grad_(True)
+        lc = ref_con(i, t)
+        gi_, gt_ = torch.autograd.grad(lc, (i, t))
+        s = i.detach().clone().requires_grad_(True)
+        lk = ref_cos(s, e)
+        gs_, = torch.autograd.grad(lk, (s,))
+        arrs[f"{name}.seed"] = np.array(seed)
+        arrs[f"{name}.con"], arrs[f"{name}.cos"] = lc, lk
+        if B <= 64:
+            arrs[f"{name}.img"], arrs[f"{name}.txt"], arrs[f"{name}.tea"] = i, t, e
+            arrs[f"{name}.d_img"], arrs[f"{name}.d_txt"], arrs[f"{name}.d_stu"] = gi_, gt_, gs_
+        else:
+            for k, gten in (("d_img", gi_), ("d_txt", gt_), ("d_stu", gs_)):
+                arrs[f"{name}.{k}.probe"] = grad_probes({f"{name}.{k}": gten})[f"{name}.{k}"]
+    # identical rows: every logit equal => loss = ln B exactly
+    same = torch.ones(8, 512)
+    arrs["same_b8.con"] = ref_con(same, same)
+    # a zero row exercises the eps=1e-12 clamp of F.normalize
+    z = torch.randn(4, 64, generator=torch.Generator().manual_seed(5))
+    z[2] = 0
+    arrs["zero_row.img"], arrs["zero_row.txt"] = z, z.flip(0).contiguous()
+    arrs["zero_row.con"] = ref_con(z, z.flip(0))
+    arrs["zero_row.cos"] = ref_cos(z, z.flip(0))
+    save("losses.npz", **arrs)
+
+
+# ----------------------------------------------------------------------------- F2 cross-modal block
+
+def gen_cross_modal(pta, ref_con):
+    arrs = {}
+    agg = pta.PatchTextAggregation.aggregation
+    for name, E, H, B, T, R, seed in (("e128", 128, 2, 3, 5, 3, 21), ("e512", 512, 8, 2, 5, 3, 22),
+                                      ("e512_c3", 512, 8, 4, 75, 8, 23)):
+        sd = synth.synth_cross_modal_state_dict(E, seed=seed)
+        cm = pta.CrossModalAttention(E, H)
+        cm.load_state_dict(sd)
+        g = torch.Generator().manual_seed(seed + 100)
+        text = torch.randn(B, T, E, generator=g)
+        patches = torch.randn(B, R, E, generator=g)
+        sent = torch.randn(B, E, generator=g)
+        # ragged, zero-padded like patch_text_aggregation.py:555-620
+        n_tok = [T] + [max(1, T - 2 - b) for b in range(1, B)]
+        n_reg = [R] + [max(1, R - b) for b in range(1, B)]
+        for b in range(B):
+            text[b, n_tok[b]:] = 0
+            patches[b, n_reg[b]:] = 0
+        at, ai = cm(text, patches)
+        tg, ig = agg(None, at), agg(None, ai)
+        glob = 0.5 * tg + 0.5 * ig
+        loss = ref_con(glob, sent)
+        grads = torch.autograd.grad(loss, list(cm.parameters()))
+        named = {k: gr for (k, _), gr in zip(cm.named_parameters(), grads)}
+        arrs.update({f"{name}.E": np.array(E), f"{name}.H": np.array(H), f"{name}.seed": np.array(seed),
+                     f"{name}.text": text, f"{name}.patches": patches, f"{name}.sentence": sent,
+                     f"{name}.n_tok": np.array(n_tok), f"{name}.n_reg": np.array(n_reg),
+                     f"{name}.attended_text": at, f"{name}.attended_image": ai,
+                     f"{name}.text_global": tg, f"{name}.image_global": ig, f"{name}.global": glob,
+                     f"{name}.loss": loss})
+        for k, v in grad_probes(named).items():
+            arrs[f"{name}.gradprobe.{k}"] = v
+        if E == 128:
+            for k, gr in named.items():
+                arrs[f"{name}.grad.{k}"] = gr
+        arrs[f"{name}.wsum"] = np.array(sum(float(v.double().sum()) for v in sd.values()))
+    save("cross_modal.npz", **arrs)
+
+
+# ----------------------------------------------------------------------------- F3 towers
+
+def all_grads(model, loss):
+    ps = [(k, p) for k, p in model.named_parameters() if p.requires_grad]
+    gs = torch.autograd.grad(loss, [p for _, p in ps], allow_unused=True)
+    return {k: (g if g is not None else torch.zeros_like(p)) for (k, p), g in zip(ps, gs)}
+
+
+def gen_towers_tiny():
+    cfg = dcfg.tiny()
+    sd = synth.synth_clip_state_dict(cfg, seed=7, gain=4.0)
+    arrs = {"wsum": np.array(sum(float(v.double().sum()) for v in sd.values()))}
+    pix = synth.synth_pixel_values(5, cfg.vision, seed=0)
+    ids = synth.synth_input_ids(5, cfg.text, seed=3, ragged=True)
+    ids[1, 1:] = cfg.text.eos_token_id           # caption with no word tokens: [BOS, EOS, pad...]
+    arrs["pixel_values"], arrs["input_ids"] = pix, ids
+    for dt, tag in ((torch.float32, "f32"), (torch.float64, "f64")):
+        m = hf_model(cfg, sd, dt)
+        vo = m.vision_model(pixel_values=pix.to(dt), output_hidden_states=True)
+        img = m.visual_projection(vo.pooler_output)
+        to = m.text_model(input_ids=ids, output_hidden_states=True)
+        txt = m.text_projection(to.pooler_output)
+        arrs[f"{tag}.image_emb"], arrs[f"{tag}.text_emb"] = img, txt
+        arrs[f"{tag}.text_last_hidden"] = to.last_hidden_state
+        arrs[f"{tag}.vision_last_hidden"] = vo.last_hidden_state
+        for i, h in enumerate(vo.hidden_states):
+            arrs[f"{tag}.vision_hidden.{i}"] = h        # [0] = post pre_layrnorm embeddings
+        for i, h in enumerate(to.hidden_states):
+            arrs[f"{tag}.text_hidden.{i}"] = h
+        if tag == "f32":
+            # scalar objective touching every output element, for parameter gradients
+            gw = torch.Generator().manual_seed(99)
+            wi = torch.randn(img.shape, generator=gw)
+            wt = torch.randn(txt.shape, generator=gw)
+            arrs["obj_w_img"], arrs["obj_w_txt"] = wi, wt
+            obj = (img * wi).sum() + (txt * wt).sum()
+            grads = all_grads(m, obj)
+            for k, v in grad_probes(grads).items():
+                arrs[f"gradprobe.{k}"] = v
+            for k, gten in grads.items():
+                if gten.numel() <= 4096:
+                    arrs[f"grad.{k}"] = gten
+            gp, = torch.autograd.grad((m.visual_projection(
+                m.vision_model(pixel_values=pix.requires_grad_(True)).pooler_output) * wi).sum(), pix)
+            arrs["grad_pixel_probe"] = grad_probes({"pixel_values": gp})["pixel_values"]
+            pix = pix.detach()
+    save("towers_tiny.npz", **arrs)
+
+
+def gen_towers_real():
+    """Real-size towers, bs=2 (weights from seeds; only outputs + per-layer statistics stored)."""
+    arrs = {}
+    for cname, mk, seed in (("b32", dcfg.vit_b32, 0), ("b16", dcfg.vit_b16, 1)):
+        cfg = mk()
+        sd = synth.synth_clip_state_dict(cfg, seed=seed, gain=3.0)
+        m = hf_model(cfg, sd)
+        pix = synth.synth_pixel_values(2, cfg.vision, seed=0)
+        ids = synth.synth_input_ids(2, cfg.text, seed=3, ragged=True)
+        with torch.no_grad():
+            vo = m.vision_model(pixel_values=pix, output_hidden_states=True)
+            img = m.visual_projection(vo.pooler_output)
+            to = m.text_model(input_ids=ids, output_hidden_states=True)
+            txt = m.text_projection(to.pooler_output)
+        arrs[f"{cname}.wsum"] = np.array(sum(float(v.double().sum()) for v in sd.values()))
+        arrs[f"{cname}.input_ids"] = ids
+        arrs[f"{cname}.image_emb"], arrs[f"{cname}.text_emb"] = img, txt
+        arrs[f"{cname}.vision_layer_stats"] = np.array(
+            [[float(h.double().mean()), float(h.double().std()), float(h.double().abs().max())]
+             for h in vo.hidden_states])
+        arrs[f"{cname}.text_layer_stats"] = np.array(
+            [[float(h.double().mean()), float(h.double().std()), float(h.double().abs().max())]
+             for h in to.hidden_states])
+        arrs[f"{cname}.vision_cls_last"] = vo.last_hidden_state[:, 0, :]
+        del m
+    save("towers_real.npz", **arrs)
+
+
+# ----------------------------------------------------------------------------- teacher glue (a4, a5, a8)
+
+def gen_teacher_glue(pta, tt, it):
+    """Runs the reference's `compute_global_embedding_batch` end to end on shell objects: real PNG
+    files, the reference's crop loop, `get_embeddings` token filter, zero padding, cross-attention,
+    aggregation, 0.5/0.5 mix.  Only the crop->tensor transform is substituted (torchvision is absent):
+    it hands back pre-made [3,S,S] tensors in [0,1], which is also what our tensor-in API takes."""
+    from PIL import Image
+    cfg = dcfg.tiny()
+    sd = synth.synth_clip_state_dict(cfg, seed=7, gain=4.0)
+    m = TensorReturning(hf_model(cfg, sd))
+    E = cfg.projection_dim
+    cmsd = synth.synth_cross_modal_state_dict(E, seed=31)
+
+    captions = ["a", "b", "c", "d"]
+    ids = synth.synth_input_ids(4, cfg.text, seed=41, ragged=True, min_len=4)
+    ids[2, 1:] = cfg.text.eos_token_id                   # no word tokens -> sentence embedding row
+    id_by_caption = dict(zip(captions, ids))
+
+    class FakeTok:
+        def __call__(self, text, **kw):
+            row = id_by_caption[text]
+            n = int((row == cfg.text.eos_token_id).int().argmax()) + 1     # unpadded, as padding=True on 1 caption
+            out = types.SimpleNamespace(input_ids=row[:n].unsqueeze(0), attention_mask=torch.ones(1, n, dtype=torch.long))
+            out.to = lambda dev: out
+            return out
+
+    text_tok = object.__new__(tt.CLIPTextTokenizer)
+    text_tok.tokenizer, text_tok.model, text_tok.device = FakeTok(), m, "cpu"
+
+    n_regions = [3, 1, 2, 0]
+    regions = synth.synth_regions(4, 3, cfg.vision, seed=2)
+    queue = []
+    patch_tok = object.__new__(it.CLIPPatchTokenizer)
+    patch_tok.clip_model, patch_tok.device = m, torch.device("cpu")
+    patch_tok.patch_transform = lambda pil: queue.pop(0)
+
+    teacher = object.__new__(pta.PatchTextAggregation)
+    nn.Module.__init__(teacher)
+    teacher.embed_dim, teacher.device = E, torch.device("cpu")
+    teacher.text_tokenizer, teacher.patch_tokenizer = text_tok, patch_tok
+    teacher.cross_modal_attention = pta.CrossModalAttention(E, 2)
+    teacher.cross_modal_attention.load_state_dict(cmsd)
+    teacher.knn_cache, teacher.use_knn_projection, teacher.advanced_tokenizer = {}, False, None
+    teacher.full_resolution = False
+
+    with tempfile.TemporaryDirectory() as d:
+        paths, boxes = [], []
+        for b in range(4):
+            pth = os.path.join(d, f"{b}.png")
+            Image.new("RGB", (96, 80), (10 * b, 20, 30)).save(pth)
+            paths.append(pth)
+            boxes.append([((4 * r, 2 * r, 40 + 4 * r, 30 + 2 * r), 0.9 - 0.1 * r) for r in range(n_regions[b])])
+            queue.extend(regions[b, r] for r in range(n_regions[b]))
+        with torch.no_grad():
+            glob = teacher.compute_global_embedding_batch(paths, captions, boxes)
+            sent = torch.stack([text_tok.aggregate_text(c) for c in captions])
+            toks = [torch.stack(text_tok.get_embeddings(c, return_token_level=True)) for c in captions]
+    arrs = {"input_ids": ids, "regions": regions, "n_regions": np.array(n_regions), "global": glob,
+            "sentence": sent, "n_tok": np.array([t.shape[0] for t in toks]), "cm_seed": np.array(31),
+            "clip_seed": np.array(7)}
+    for b, t in enumerate(toks):
+        arrs[f"tokens.{b}"] = t
+    save("teacher_glue.npz", **arrs)
+
+
+# ----------------------------------------------------------------------------- F4 full step, config c1
+
+def gen_step_c1(ref_con, ref_cos):
+    """BASELINE config c1: ViT-B/32 + text tower, bs=8, the reference's step arithmetic
+    (training/CLIP_image_distillation.py:594-628) with the teacher image embedding given."""
+    cfg = dcfg.vit_b32()
+    sd = synth.synth_clip_state_dict(cfg, seed=0, gain=3.0)
+    m = TensorReturning(hf_model(cfg, sd))
+    m.m.train()                                                 # dropout is 0; train() as Lightning would
+    B = 8
+    pix = synth.synth_pixel_values(B, cfg.vision, seed=0)
+    ids = synth.synth_input_ids(B, cfg.text, seed=3, ragged=True, min_len=8)
+    t_img = synth.synth_embeddings(B, cfg.projection_dim, seed=1)
+    t_txt = synth.synth_embeddings(B, cfg.projection_dim, seed=5)
+    s_img = m.get_image_features(pixel_values=pix).float()
+    s_txt = m.get_text_features(input_ids=ids).float()
+    l_img = ref_cos(s_img, t_img)
+    l_txt = ref_cos(s_txt, t_txt)
+    l_con = ref_con(s_img, s_txt)
+    loss = l_img + l_txt + 1.0 * l_con
+    grads = all_grads(m.m, loss)
+    arrs = {"input_ids": ids, "image_emb": s_img, "text_emb": s_txt, "loss_image": l_img, "loss_text": l_txt,
+            "loss_contrastive": l_con, "loss": loss,
+            "wsum": np.array(sum(float(v.double().sum()) for v in sd.values()))}
+    for k, v in grad_probes(grads).items():
+        arrs[f"gradprobe.{k}"] = v
+    # shared-text-forward variant (north_star regime): teacher sentence embedding = detached student text
+    l_txt_shared = ref_cos(s_txt, s_txt.detach())
+    arrs["loss_text_shared"] = l_txt_shared
+    save("step_c1.npz", **arrs)
+
+
+def main():
+    which = set(sys.argv[1:])
+    pta, tt, it = import_reference_teacher()
+    ref_con, ref_cos = lift_losses()
+    if not which or "losses" in which:
+        gen_losses(ref_con, ref_cos)
+    if not which or "cross_modal" in which:
+        gen_cross_modal(pta, ref_con)
+    if not which or "towers_tiny" in which:
+        gen_towers_tiny()
+    if not which or "teacher_glue" in which:
+        gen_teacher_glue(pta, tt, it)
+    if not which or "towers_real" in which:
+        gen_towers_real()
+    if not which or "step_c1" in which:
+        gen_step_c1(ref_con, ref_cos)
+
+
+if __name__ == "__main__":
+    main()
