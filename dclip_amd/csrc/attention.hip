@@ -1,0 +1,376 @@
+// Multi-head self-attention core (head_dim 64) on v_mfma_f32_16x16x4_f32, forward and backward.
+//
+// One workgroup (4 waves) owns a 64-row tile of one (batch, head); each wave owns 16 of those rows and
+// sweeps 64-row tiles of the other index with an online softmax (fwd) or with the saved log-sum-exp (bwd),
+// so the S x S probabilities never reach HBM.  CLIP sequences are short (50 / 77 / 197 / 257): whole
+// problems sit in one or a few tiles and the kernel is bounded by reading q,k,v once (12 B/element/head).
+//
+// LDS image of a [64 rows][64 floats] tile: 256-B rows of sixteen 16-B slots, slot' = slot ^ (row & 15).
+//   * as an MFMA A operand (or a B operand that is K-major, e.g. K in Q K^T) a lane (r = lane&15,
+//     quarter = lane>>4) reads slot 4g+quarter of row r with one ds_read_b128 and gets the contraction
+//     indices 16g + 4*quarter + {0..3}: four MFMAs per read, conflict free.
+//   * as a B operand indexed [contraction row][column] (V in P V, K in dS K, ...) a lane reads
+//     element (row = 16g + 4*quarter + r, col = 16*nt + (lane&15)) with ds_read_b32, conflict free.
+// Probability-like tiles go from the accumulator layout (col on the lane) back to an A operand through a
+// per-wave [16][68] LDS scratch.
+#include "common.h"
+
+namespace {
+
+constexpr int TS = 64;       // tile rows
+constexpr int HD = 64;       // head dim
+constexpr int SCR = 68;      // scratch row stride (floats)
+constexpr float kScale = 0.125f;  // 64^-0.5
+
+__device__ __forceinline__ int tile_off(int row, int col) {
+  return row * HD + ((((col >> 2) ^ (row & 15)) << 2) | (col & 3));
+}
+
+// global rows [row0, row0+64) x 64 floats (row stride ld) -> swizzled LDS tile; rows >= nrows are zero
+__device__ __forceinline__ void stage_tile(float* tile, const float* __restrict__ g, int row0, int nrows, size_t ld) {
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    int id = threadIdx.x + c * 256;
+    int row = id >> 4, slot = id & 15;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (row0 + row < nrows) v = *reinterpret_cast<const f32x4*>(g + (size_t)(row0 + row) * ld + slot * 4);
+    *reinterpret_cast<f32x4*>(tile + row * HD + ((slot ^ (row & 15)) << 2)) = v;
+  }
+}
+
+// fragment for rows [rbase, rbase+16): contraction group g
+__device__ __forceinline__ f32x4 frag_k(const float* tile, int rbase, int g, int lane) {
+  int row = rbase + (lane & 15);
+  int slot = 4 * g + (lane >> 4);
+  return *reinterpret_cast<const f32x4*>(tile + row * HD + ((slot ^ (row & 15)) << 2));
+}
+
+// acc[nt] (16 x 16 each) += A_rows(16 x 64 via regs af[g]) * T^T where T tile rows are the output columns
+__device__ __forceinline__ void mma_rows_x_tileT(f32x4 (&acc)[4], const f32x4 (&af)[4], const float* tile, int lane) {
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      f32x4 bf = frag_k(tile, 16 * nt, g, lane);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[g][r], bf[r], acc[nt], 0, 0, 0);
+    }
+}
+
+// acc[nt] (16 x 16 over columns 16nt..) += P(16 x 64, per-wave scratch) * T (64 x 64 tile, row = contraction)
+__device__ __forceinline__ void mma_scratch_x_tile(f32x4 (&acc)[4], const float* scr, const float* tile, int lane) {
+  const int qd = lane >> 4, l15 = lane & 15;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    f32x4 pf = *reinterpret_cast<const f32x4*>(scr + l15 * SCR + 16 * g + 4 * qd);
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float b = tile[tile_off(16 * g + 4 * qd + r, 16 * nt + l15)];
+        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(pf[r], b, acc[nt], 0, 0, 0);
+      }
+  }
+}
+
+__device__ __forceinline__ void zero4(f32x4 (&a)[4]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) a[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+}
+
+// ------------------------------------------------------------------------------------------- forward
+template <bool CAUSAL>
+__global__ void __launch_bounds__(256) attn_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ out,
+                                                       float* __restrict__ lse, int B, int S, int H) {
+  __shared__ __attribute__((aligned(16))) float t0[TS * HD];
+  __shared__ __attribute__((aligned(16))) float t1[TS * HD];
+  __shared__ __attribute__((aligned(16))) float scratch[4 * 16 * SCR];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int qd = lane >> 4, l15 = lane & 15;
+  const int bh = blockIdx.x, b = bh / H, h = bh % H;
+  const int q0 = blockIdx.y * TS;
+  const int D = H * HD;
+  const size_t ld = (size_t)3 * D;
+  const float* base = qkv + (size_t)b * S * ld + h * HD;
+  float* scr = scratch + wave * 16 * SCR;
+
+  stage_tile(t0, base, q0, S, ld);
+  __syncthreads();
+  f32x4 qf[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) qf[g] = frag_k(t0, 16 * wave, g, lane);
+
+  float m[4], l[4];
+  f32x4 o[4];
+  zero4(o);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    m[r] = -INFINITY;
+    l[r] = 0.f;
+  }
+  int nkt = (S + TS - 1) / TS;
+  if (CAUSAL) nkt = min(nkt, (int)blockIdx.y + 1);
+  for (int kt = 0; kt < nkt; ++kt) {
+    __syncthreads();  // everyone is done with t0/t1 of the previous tile (and with the Q fragments load)
+    stage_tile(t0, base + D, kt * TS, S, ld);
+    stage_tile(t1, base + 2 * D, kt * TS, S, ld);
+    __syncthreads();
+    f32x4 s[4];
+    zero4(s);
+    mma_rows_x_tileT(s, qf, t0, lane);
+    float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      const int key = kt * TS + nt * 16 + l15;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int qrow = q0 + 16 * wave + 4 * qd + r;
+        float v = s[nt][r] * kScale;
+        if (key >= S || (CAUSAL && key > qrow)) v = -INFINITY;
+        s[nt][r] = v;
+        mx[r] = fmaxf(mx[r], v);
+      }
+    }
+    float alpha[4], rs[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float mn = fmaxf(m[r], quarter_max(mx[r]));
+      const float msafe = (mn == -INFINITY) ? 0.f : mn;
+      alpha[r] = __expf(m[r] - msafe);  // m = -inf -> 0
+      m[r] = mn;
+      rs[r] = 0.f;
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        float p = __expf(s[nt][r] - msafe);
+        s[nt][r] = p;
+        rs[r] += p;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      l[r] = l[r] * alpha[r] + quarter_sum(rs[r]);
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        o[nt][r] *= alpha[r];
+        scr[(4 * qd + r) * SCR + nt * 16 + l15] = s[nt][r];
+      }
+    }
+    __syncthreads();
+    mma_scratch_x_tile(o, scr, t1, lane);
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = q0 + 16 * wave + 4 * qd + r;
+    if (row < S) {
+      const float inv = 1.0f / l[r];
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) out[((size_t)b * S + row) * D + h * HD + nt * 16 + l15] = o[nt][r] * inv;
+      if (l15 == 0) lse[(size_t)bh * S + row] = m[r] + __logf(l[r]);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------- backward: dQ
+// also writes delta[bh, row] = sum_d dO * O for the dK/dV kernel
+template <bool CAUSAL>
+__global__ void __launch_bounds__(256) attn_bwd_dq_kernel(const float* __restrict__ qkv, const float* __restrict__ out,
+                                                          const float* __restrict__ dout, const float* __restrict__ lse,
+                                                          float* __restrict__ dqkv, float* __restrict__ delta, int B,
+                                                          int S, int H) {
+  __shared__ __attribute__((aligned(16))) float t0[TS * HD];
+  __shared__ __attribute__((aligned(16))) float t1[TS * HD];
+  __shared__ __attribute__((aligned(16))) float scratch[4 * 16 * SCR];
+  __shared__ float dl_s[TS];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int qd = lane >> 4, l15 = lane & 15;
+  const int bh = blockIdx.x, b = bh / H, h = bh % H;
+  const int q0 = blockIdx.y * TS;
+  const int D = H * HD;
+  const size_t ld = (size_t)3 * D;
+  const float* base = qkv + (size_t)b * S * ld + h * HD;
+  const float* obase = out + (size_t)b * S * D + h * HD;
+  const float* dobase = dout + (size_t)b * S * D + h * HD;
+  float* scr = scratch + wave * 16 * SCR;
+
+  {  // delta: 4 threads per row, 16 floats each
+    const int row = threadIdx.x >> 2, part = threadIdx.x & 3;
+    float s = 0.f;
+    if (q0 + row < S) {
+      const f32x4* po = reinterpret_cast<const f32x4*>(obase + (size_t)(q0 + row) * D + part * 16);
+      const f32x4* pd = reinterpret_cast<const f32x4*>(dobase + (size_t)(q0 + row) * D + part * 16);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        f32x4 a = po[i], c = pd[i];
+        s += (a[0] * c[0] + a[1] * c[1]) + (a[2] * c[2] + a[3] * c[3]);
+      }
+    }
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    if (part == 0) {
+      dl_s[row] = s;
+      if (q0 + row < S) delta[(size_t)bh * S + q0 + row] = s;
+    }
+  }
+  stage_tile(t0, base, q0, S, ld);
+  stage_tile(t1, dobase, q0, S, (size_t)D);
+  __syncthreads();
+  f32x4 qf[4], dof[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    qf[g] = frag_k(t0, 16 * wave, g, lane);
+    dof[g] = frag_k(t1, 16 * wave, g, lane);
+  }
+  float lse_r[4], dl[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = q0 + 16 * wave + 4 * qd + r;
+    lse_r[r] = (row < S) ? lse[(size_t)bh * S + row] : 0.f;
+    dl[r] = dl_s[16 * wave + 4 * qd + r];
+  }
+  f32x4 dq[4];
+  zero4(dq);
+  int nkt = (S + TS - 1) / TS;
+  if (CAUSAL) nkt = min(nkt, (int)blockIdx.y + 1);
+  for (int kt = 0; kt < nkt; ++kt) {
+    __syncthreads();
+    stage_tile(t0, base + D, kt * TS, S, ld);
+    stage_tile(t1, base + 2 * D, kt * TS, S, ld);
+    __syncthreads();
+    f32x4 s[4], dp[4];
+    zero4(s);
+    zero4(dp);
+    mma_rows_x_tileT(s, qf, t0, lane);
+    mma_rows_x_tileT(dp, dof, t1, lane);
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      const int key = kt * TS + nt * 16 + l15;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int qrow = q0 + 16 * wave + 4 * qd + r;
+        const bool masked = key >= S || (CAUSAL && key > qrow);
+        const float p = masked ? 0.f : __expf(s[nt][r] * kScale - lse_r[r]);
+        scr[(4 * qd + r) * SCR + nt * 16 + l15] = p * (dp[nt][r] - dl[r]) * kScale;
+      }
+    }
+    __syncthreads();
+    mma_scratch_x_tile(dq, scr, t0, lane);
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = q0 + 16 * wave + 4 * qd + r;
+    if (row < S)
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) dqkv[((size_t)b * S + row) * ld + h * HD + nt * 16 + l15] = dq[nt][r];
+  }
+}
+
+// ------------------------------------------------------------------------------------------- backward: dK, dV
+template <bool CAUSAL>
+__global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
+                                                           const float* __restrict__ lse, const float* __restrict__ delta,
+                                                           float* __restrict__ dqkv, int B, int S, int H) {
+  __shared__ __attribute__((aligned(16))) float t0[TS * HD];
+  __shared__ __attribute__((aligned(16))) float t1[TS * HD];
+  __shared__ __attribute__((aligned(16))) float scratch_p[4 * 16 * SCR];
+  __shared__ __attribute__((aligned(16))) float scratch_s[4 * 16 * SCR];
+  __shared__ float lse_s[TS], dl_s[TS];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int qd = lane >> 4, l15 = lane & 15;
+  const int bh = blockIdx.x, b = bh / H, h = bh % H;
+  const int k0 = blockIdx.y * TS;
+  const int D = H * HD;
+  const size_t ld = (size_t)3 * D;
+  const float* base = qkv + (size_t)b * S * ld + h * HD;
+  const float* dobase = dout + (size_t)b * S * D + h * HD;
+  float* scp = scratch_p + wave * 16 * SCR;
+  float* scs = scratch_s + wave * 16 * SCR;
+
+  stage_tile(t0, base + D, k0, S, ld);
+  stage_tile(t1, base + 2 * D, k0, S, ld);
+  __syncthreads();
+  f32x4 kf[4], vf[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    kf[g] = frag_k(t0, 16 * wave, g, lane);
+    vf[g] = frag_k(t1, 16 * wave, g, lane);
+  }
+  f32x4 dk[4], dv[4];
+  zero4(dk);
+  zero4(dv);
+  const int nqt = (S + TS - 1) / TS;
+  for (int qt = CAUSAL ? (int)blockIdx.y : 0; qt < nqt; ++qt) {
+    const int q0 = qt * TS;
+    __syncthreads();
+    stage_tile(t0, base, q0, S, ld);
+    stage_tile(t1, dobase, q0, S, (size_t)D);
+    if (threadIdx.x < TS) {
+      const int q = q0 + threadIdx.x;
+      lse_s[threadIdx.x] = (q < S) ? lse[(size_t)bh * S + q] : 0.f;
+      dl_s[threadIdx.x] = (q < S) ? delta[(size_t)bh * S + q] : 0.f;
+    }
+    __syncthreads();
+    f32x4 st[4], dpt[4];
+    zero4(st);
+    zero4(dpt);
+    mma_rows_x_tileT(st, kf, t0, lane);    // [key, q] = K Q^T
+    mma_rows_x_tileT(dpt, vf, t1, lane);   // [key, q] = V dO^T
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      const int ql = nt * 16 + l15, q = q0 + ql;
+      const float lq = lse_s[ql], dq_ = dl_s[ql];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = k0 + 16 * wave + 4 * qd + r;
+        const bool masked = key >= S || q >= S || (CAUSAL && key > q);
+        const float p = masked ? 0.f : __expf(st[nt][r] * kScale - lq);
+        scp[(4 * qd + r) * SCR + ql] = p;
+        scs[(4 * qd + r) * SCR + ql] = p * (dpt[nt][r] - dq_) * kScale;
+      }
+    }
+    __syncthreads();
+    mma_scratch_x_tile(dv, scp, t1, lane);  // dV += P^T dO
+    mma_scratch_x_tile(dk, scs, t0, lane);  // dK += dS^T Q
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int key = k0 + 16 * wave + 4 * qd + r;
+    if (key < S)
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        const size_t o = ((size_t)b * S + key) * ld + h * HD + nt * 16 + l15;
+        dqkv[o + D] = dk[nt][r];
+        dqkv[o + 2 * D] = dv[nt][r];
+      }
+  }
+}
+
+}  // namespace
+
+DCLIP_API int dclip_attention_fwd(const float* qkv, float* out, float* lse, int B, int S, int H, int causal,
+                                  void* stream) {
+  DCLIP_REQUIRE(qkv && out && lse, "attention_fwd: null pointer");
+  DCLIP_REQUIRE(B > 0 && S > 0 && H > 0, "attention_fwd: bad shape B=%d S=%d H=%d", B, S, H);
+  dim3 grid(B * H, cdiv(S, TS)), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (causal) hipLaunchKernelGGL((attn_fwd_kernel<true>), grid, block, 0, st, qkv, out, lse, B, S, H);
+  else hipLaunchKernelGGL((attn_fwd_kernel<false>), grid, block, 0, st, qkv, out, lse, B, S, H);
+  DCLIP_CHECK_LAUNCH("attention_fwd");
+  return DCLIP_OK;
+}
+
+DCLIP_API int dclip_attention_bwd(const float* qkv, const float* out, const float* dout, const float* lse,
+                                  float* dqkv, float* delta, int B, int S, int H, int causal, void* stream) {
+  DCLIP_REQUIRE(qkv && out && dout && lse && dqkv && delta, "attention_bwd: null pointer");
+  DCLIP_REQUIRE(B > 0 && S > 0 && H > 0, "attention_bwd: bad shape B=%d S=%d H=%d", B, S, H);
+  dim3 grid(B * H, cdiv(S, TS)), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (causal) {
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<true>), grid, block, 0, st, qkv, out, dout, lse, dqkv, delta, B, S, H);
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<true>), grid, block, 0, st, qkv, dout, lse, delta, dqkv, B, S, H);
+  } else {
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<false>), grid, block, 0, st, qkv, out, dout, lse, dqkv, delta, B, S, H);
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<false>), grid, block, 0, st, qkv, dout, lse, delta, dqkv, B, S, H);
+  }
+  DCLIP_CHECK_LAUNCH("attention_bwd");
+  return DCLIP_OK;
+}

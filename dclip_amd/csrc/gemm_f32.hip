@@ -1,0 +1,504 @@
+// fp32 GEMM on the CDNA4 matrix cores (v_mfma_f32_32x32x2_f32: exact f32, 64 FLOP/clk/SIMD).
+//
+// C[M,N] = epilogue( alpha * sum_k A(m,k) B(k,n) ),  either operand K-major or M/N-major.
+//
+// Tiling (one workgroup = 4 waves = 256 lanes):
+//   block tile  BM x BN x 32,  waves in a WM x WN grid, each wave owns (BM/WM) x (BN/WN) as
+//   MT x NT MFMA tiles of 32x32 (16 accumulator registers each).
+// LDS images (double buffered, one barrier per K-tile):
+//   K-major operand  [rows][32 floats] = 128-B rows, 16-B slots XOR-swizzled with (row>>1)&7 so that a
+//     ds_read_b128 of one slot down 16 rows touches 16 distinct slots of the 256-B bank row.  A lane
+//     (row = lane&31, half = lane>>5) reads slot 2g+half of k-group g and gets k = 8g + 4*half + {0..3}.
+//   M/N-major operand [32][rows]: a lane reads element (k, row0 + (lane&31)) with ds_read_b32 —
+//     32 consecutive floats per half-wave, conflict free; the same k = 8g + 4*half + r is chosen.
+//   The MFMA only needs A and B to agree on which k each lane-half supplies, so the k permutation is free.
+// Global -> LDS goes through registers (global_load_dwordx4, zero-filled out of range) one K-tile ahead.
+// Workgroup ids are remapped so that the 8 XCDs each walk a contiguous band of row-tiles (A panel reuse in
+// that XCD's L2; B, the weight, is small and shared through the Infinity Cache).
+#include "common.h"
+
+namespace {
+
+constexpr int BK = 32;
+
+struct GemmParams {
+  const float* A;
+  const float* B;
+  float* C;
+  const float* bias;
+  const float* residual;
+  float* aux;
+  int M, N, K;
+  int lda, ldb, ldc;
+  int epilogue;
+  float alpha;
+  int tiles_m, tiles_n;
+  int k_per_split;  // multiple of BK
+  float* slab;      // split-K partials [split][M][N] or nullptr
+  // contrastive-loss modes (mode 0 = plain GEMM)
+  int mode;              // 1: row-LSE partials over this tile's columns, 2: dZ tile
+  const float* lse_row;  // mode 2
+  const float* lse_col;  // mode 2
+  float* part_m;         // mode 1: [tiles_n*WN][M] running max
+  float* part_s;         // mode 1: [tiles_n*WN][M] sum exp(z - max)
+  int offset;            // column of row i's positive = i + offset
+};
+
+enum { MODE_GEMM = 0, MODE_LSE = 1, MODE_DZ = 2 };
+
+__device__ __forceinline__ void apply_epilogue_store(const GemmParams& p, int row, int col, float v) {
+  v *= p.alpha;
+  size_t off = (size_t)row * p.ldc + col;
+  if (p.epilogue & DCLIP_EPI_BIAS) v += p.bias[col];
+  if (p.epilogue & DCLIP_EPI_GELU) {
+    if (p.aux) p.aux[off] = v;
+    v = quick_gelu_f(v);
+  }
+  if (p.epilogue & DCLIP_EPI_DGELU) v *= quick_gelu_grad_f(p.aux[off]);
+  if (p.epilogue & DCLIP_EPI_RESIDUAL) v += p.residual[off];
+  if (p.epilogue & DCLIP_EPI_ACCUM) v += p.C[off];
+  p.C[off] = v;
+}
+
+// XCD-aware, bijective remap of the linear workgroup id (blocks b and b+8 share an XCD).
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, i = bid >> 3;
+  int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + i;
+}
+
+template <int BM, int BN, int WM, int WN, bool A_KMAJOR, bool B_KMAJOR>
+__global__ void __launch_bounds__(256, 2) gemm_f32_kernel(GemmParams p) {
+  constexpr int TM = BM / WM, TN = BN / WN;
+  constexpr int MT = TM / 32, NT = TN / 32;
+  constexpr int A_CHUNKS = BM * BK / 4 / 256;  // 16-byte chunks per thread per K-tile
+  constexpr int B_CHUNKS = BN * BK / 4 / 256;
+  static_assert(WM * WN == 4, "4 waves");
+  static_assert(A_CHUNKS >= 1 && B_CHUNKS >= 1, "tile too small");
+
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* As = lds;                      // [2][BM*BK]
+  float* Bs = lds + 2 * BM * BK;        // [2][BN*BK]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int l31 = lane & 31, half = lane >> 5;
+
+  const int nwg = p.tiles_m * p.tiles_n;
+  const int swz = xcd_remap(blockIdx.x, nwg);
+  const int tile_m = swz / p.tiles_n, tile_n = swz % p.tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int kbeg = blockIdx.y * p.k_per_split;
+  const int kend = min(p.K, kbeg + p.k_per_split);
+  const int nk = (kend - kbeg + BK - 1) / BK;
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  f32x4 ra[A_CHUNKS], rb[B_CHUNKS];
+
+  auto load_tile = [&](int kt) {
+    const int k0 = kbeg + kt * BK;
+#pragma unroll
+    for (int c = 0; c < A_CHUNKS; ++c) {
+      int id = tid + c * 256;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (A_KMAJOR) {  // rows of 8 chunks
+        int row = id >> 3, slot = id & 7;
+        int gm = m0 + row, gk = k0 + slot * 4;
+        if (gm < p.M && gk < kend) {
+          const float* src = p.A + (size_t)gm * p.lda + gk;
+          if (gk + 3 < kend) v = *reinterpret_cast<const f32x4*>(src);
+          else  // ragged K tail (K % 4 != 0): element-wise
+            for (int e = 0; e < 4; ++e) v[e] = (gk + e < kend) ? src[e] : 0.f;
+        }
+      } else {  // [32][BM]: BM/4 chunks per k row
+        int kk = id / (BM / 4), c4 = id % (BM / 4);
+        int gk = k0 + kk, gm = m0 + c4 * 4;
+        if (gk < kend && gm < p.M) v = *reinterpret_cast<const f32x4*>(p.A + (size_t)gk * p.lda + gm);
+      }
+      ra[c] = v;
+    }
+#pragma unroll
+    for (int c = 0; c < B_CHUNKS; ++c) {
+      int id = tid + c * 256;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (B_KMAJOR) {
+        int row = id >> 3, slot = id & 7;
+        int gn = n0 + row, gk = k0 + slot * 4;
+        if (gn < p.N && gk < kend) {
+          const float* src = p.B + (size_t)gn * p.ldb + gk;
+          if (gk + 3 < kend) v = *reinterpret_cast<const f32x4*>(src);
+          else
+            for (int e = 0; e < 4; ++e) v[e] = (gk + e < kend) ? src[e] : 0.f;
+        }
+      } else {
+        int kk = id / (BN / 4), c4 = id % (BN / 4);
+        int gk = k0 + kk, gn = n0 + c4 * 4;
+        if (gk < kend && gn < p.N) v = *reinterpret_cast<const f32x4*>(p.B + (size_t)gk * p.ldb + gn);
+      }
+      rb[c] = v;
+    }
+  };
+
+  auto store_tile = [&](int buf) {
+    float* a = As + buf * BM * BK;
+    float* b = Bs + buf * BN * BK;
+#pragma unroll
+    for (int c = 0; c < A_CHUNKS; ++c) {
+      int id = tid + c * 256;
+      if (A_KMAJOR) {
+        int row = id >> 3, slot = id & 7;
+        *reinterpret_cast<f32x4*>(a + row * BK + ((slot ^ ((row >> 1) & 7)) << 2)) = ra[c];
+      } else {
+        *reinterpret_cast<f32x4*>(a + id * 4) = ra[c];  // [kk][BM] is exactly chunk order
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < B_CHUNKS; ++c) {
+      int id = tid + c * 256;
+      if (B_KMAJOR) {
+        int row = id >> 3, slot = id & 7;
+        *reinterpret_cast<f32x4*>(b + row * BK + ((slot ^ ((row >> 1) & 7)) << 2)) = rb[c];
+      } else {
+        *reinterpret_cast<f32x4*>(b + id * 4) = rb[c];
+      }
+    }
+  };
+
+  auto compute_tile = [&](int buf) {
+    const float* a = As + buf * BM * BK;
+    const float* b = Bs + buf * BN * BK;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      f32x4 fa[MT], fb[NT];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        int row = wm * TM + i * 32 + l31;
+        if (A_KMAJOR) {
+          fa[i] = *reinterpret_cast<const f32x4*>(a + row * BK + (((2 * g + half) ^ ((row >> 1) & 7)) << 2));
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) fa[i][r] = a[(8 * g + 4 * half + r) * BM + row];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        int row = wn * TN + j * 32 + l31;
+        if (B_KMAJOR) {
+          fb[j] = *reinterpret_cast<const f32x4*>(b + row * BK + (((2 * g + half) ^ ((row >> 1) & 7)) << 2));
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) fb[j][r] = b[(8 * g + 4 * half + r) * BN + row];
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][r], fb[j][r], acc[i][j], 0, 0, 0);
+    }
+  };
+
+  if (nk > 0) {
+    load_tile(0);
+    store_tile(0);
+  }
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) load_tile(kt + 1);
+    compute_tile(buf);
+    if (kt + 1 < nk) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+
+  if (p.mode == MODE_LSE) {
+    // z = alpha * acc (alpha = 1/temperature).  Per row: max and sum-exp over this wave's TN columns,
+    // reduced over the 32 lanes that share a row with xor-shuffles; partial slot = tile_n*WN + wn.
+    const int slot = tile_n * WN + wn;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        float v[NT], mx = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const int col = n0 + wn * TN + j * 32 + l31;
+          v[j] = (col < p.N) ? acc[i][j][r] * p.alpha : -INFINITY;
+          mx = fmaxf(mx, v[j]);
+        }
+        mx = half_max(mx);
+        const float msafe = (mx == -INFINITY) ? 0.f : mx;
+        float sum = 0.f;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) sum += __expf(v[j] - msafe);
+        sum = half_sum(sum);
+        if (l31 == 0 && row < p.M) {
+          p.part_m[(size_t)slot * p.M + row] = mx;
+          p.part_s[(size_t)slot * p.M + row] = sum;
+        }
+      }
+    return;
+  }
+  if (p.mode == MODE_DZ) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int col = n0 + wn * TN + j * 32 + l31;
+        const float lc = (col < p.N) ? p.lse_col[col] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = m0 + wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          if (row < p.M && col < p.N) {
+            const float z = acc[i][j][r] * p.alpha;
+            float w = __expf(z - p.lse_row[row]) + __expf(z - lc);
+            if (col == row + p.offset) w -= 2.0f;
+            p.C[(size_t)row * p.ldc + col] = w;
+          }
+        }
+      }
+    return;
+  }
+  // epilogue: acc register r of tile (i,j) is C[row = (r&3) + 8*(r>>2) + 4*half][col = lane&31]
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int col = n0 + wn * TN + j * 32 + l31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (row < p.M && col < p.N) {
+          if (p.slab) {
+            p.slab[((size_t)blockIdx.y * p.M + row) * p.N + col] = acc[i][j][r];
+          } else {
+            apply_epilogue_store(p, row, col, acc[i][j][r]);
+          }
+        }
+      }
+    }
+}
+
+// Sums split-K slabs in fixed order, then applies the epilogue.  One float4 per thread.
+__global__ void __launch_bounds__(256) splitk_reduce_kernel(GemmParams p, int splits) {
+  const size_t total4 = (size_t)p.M * p.N / 4;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4;
+       i += (size_t)gridDim.x * blockDim.x) {
+    f32x4 s = *reinterpret_cast<const f32x4*>(p.slab + i * 4);
+    for (int z = 1; z < splits; ++z) s += *reinterpret_cast<const f32x4*>(p.slab + (size_t)z * p.M * p.N + i * 4);
+    const int row = (int)((i * 4) / p.N), col = (int)((i * 4) % p.N);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) apply_epilogue_store(p, row, col + e, s[e]);
+  }
+}
+
+template <int BM, int BN, int WM, int WN>
+int launch_cfg(const GemmParams& p, int layout, int splits, hipStream_t st) {
+  dim3 grid(p.tiles_m * p.tiles_n, splits);
+  const size_t lds = (size_t)2 * (BM + BN) * BK * sizeof(float);
+  const bool ak = layout & DCLIP_A_KMAJOR, bk = layout & DCLIP_B_KMAJOR;
+  if (ak && bk)
+    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, true, true>), grid, dim3(256), lds, st, p);
+  else if (ak && !bk)
+    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, true, false>), grid, dim3(256), lds, st, p);
+  else if (!ak && bk)
+    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, false, true>), grid, dim3(256), lds, st, p);
+  else
+    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, false, false>), grid, dim3(256), lds, st, p);
+  return 0;
+}
+
+constexpr int NUM_CU = 256;
+
+struct Plan {
+  int bm, bn, splits, k_per_split;
+};
+
+// Tile / split-K choice.  f32 MFMA is slow enough (64 cycles per 32x32x2) that even a 64x64 block tile is
+// compute-bound, so the choice is about filling 256 CUs x 2 resident workgroups with few idle tails.
+Plan make_plan(int M, int N, int K, int split_k) {
+  const int cand[4][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}};
+  double best = 1e300;
+  Plan pl{128, 128, 1, K};
+  for (auto& c : cand) {
+    const int bm = c[0], bn = c[1];
+    const long tiles = (long)cdiv(M, bm) * cdiv(N, bn);
+    int smax = split_k > 0 ? split_k : 32;
+    for (int s = (split_k > 0 ? split_k : 1); s <= smax; s *= 2) {
+      int kps = cdiv(cdiv(K, s), BK) * BK;
+      int s_eff = cdiv(K, kps);
+      if (split_k <= 0 && s > 1 && kps < 256) break;
+      const long wgs = tiles * s_eff;
+      // two workgroups share a CU's matrix pipes: time ~ ceil(wgs / 512) rounds of 2 tiles per CU
+      const double slots = 2.0 * NUM_CU;
+      const double rounds = (double)((wgs + (long)slots - 1) / (long)slots);
+      // per-workgroup cost ~ MFMA cycles + fixed prologue/epilogue overhead (in units of k-steps)
+      const double per = (double)bm * bn * ((double)kps + 96.0);
+      // small tiles re-read operands more: mild penalty
+      const double eff = (bm == 128 && bn == 128) ? 1.0 : (bm == 64 && bn == 64 ? 1.10 : 1.05);
+      double cost = rounds * per * eff;
+      if (s_eff > 1) cost += 3.0 * (double)M * N * s_eff / 32.0;  // slab write + reduce traffic
+      if (cost < best) {
+        best = cost;
+        pl = Plan{bm, bn, s_eff, kps};
+      }
+      if (split_k > 0) break;
+    }
+  }
+  return pl;
+}
+
+}  // namespace
+
+DCLIP_API size_t dclip_gemm_f32_workspace(int M, int N, int K, int layout, int split_k) {
+  (void)layout;
+  Plan pl = make_plan(M, N, K, split_k);
+  return pl.splits > 1 ? (size_t)pl.splits * M * N * sizeof(float) : 0;
+}
+
+DCLIP_API int dclip_gemm_f32(const float* A, const float* B, float* C, const float* bias,
+                             const float* residual, float* aux, int M, int N, int K, int lda, int ldb, int ldc,
+                             int layout, int epilogue, float alpha, int split_k, void* workspace,
+                             size_t workspace_bytes, void* stream) {
+  DCLIP_REQUIRE(A && B && C, "gemm_f32: null operand");
+  DCLIP_REQUIRE(M > 0 && N > 0 && K > 0, "gemm_f32: bad shape M=%d N=%d K=%d", M, N, K);
+  const bool ak = layout & DCLIP_A_KMAJOR, bk = layout & DCLIP_B_KMAJOR;
+  DCLIP_REQUIRE((ak || M % 4 == 0) && lda % 4 == 0 && lda >= (ak ? K : M),
+                "gemm_f32: lda (and M when A is [K][M]) must be a multiple of 4 (M=%d K=%d lda=%d)", M, K, lda);
+  DCLIP_REQUIRE((bk || N % 4 == 0) && ldb % 4 == 0 && ldb >= (bk ? K : N),
+                "gemm_f32: ldb (and N when B is [K][N]) must be a multiple of 4 (N=%d K=%d ldb=%d)", N, K, ldb);
+  DCLIP_REQUIRE(N % 4 == 0 && ldc % 4 == 0 && ldc >= N, "gemm_f32: N / ldc must be a multiple of 4");
+  DCLIP_REQUIRE(((uintptr_t)A | (uintptr_t)B | (uintptr_t)C) % 16 == 0, "gemm_f32: operands must be 16-byte aligned");
+  DCLIP_REQUIRE(!(epilogue & DCLIP_EPI_BIAS) || bias, "gemm_f32: BIAS without bias");
+  DCLIP_REQUIRE(!(epilogue & DCLIP_EPI_RESIDUAL) || residual, "gemm_f32: RESIDUAL without residual");
+  DCLIP_REQUIRE(!(epilogue & DCLIP_EPI_DGELU) || aux, "gemm_f32: DGELU without aux");
+
+  Plan pl = make_plan(M, N, K, split_k);
+  GemmParams p{A, B, C, bias, residual, aux, M, N, K, lda, ldb, ldc, epilogue, alpha,
+               cdiv(M, pl.bm), cdiv(N, pl.bn), pl.k_per_split, nullptr,
+               MODE_GEMM, nullptr, nullptr, nullptr, nullptr, 0};
+  if (pl.splits > 1) {
+    const size_t need = (size_t)pl.splits * M * N * sizeof(float);
+    if (!workspace || workspace_bytes < need) {
+      dclip_set_error("gemm_f32: split-K needs %zu workspace bytes, got %zu", need, workspace_bytes);
+      return DCLIP_EWORKSPACE;
+    }
+    p.slab = (float*)workspace;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  if (pl.bm == 128 && pl.bn == 128) launch_cfg<128, 128, 2, 2>(p, layout, pl.splits, st);
+  else if (pl.bm == 128 && pl.bn == 64) launch_cfg<128, 64, 2, 2>(p, layout, pl.splits, st);
+  else if (pl.bm == 64 && pl.bn == 128) launch_cfg<64, 128, 2, 2>(p, layout, pl.splits, st);
+  else launch_cfg<64, 64, 2, 2>(p, layout, pl.splits, st);
+  DCLIP_CHECK_LAUNCH("gemm_f32");
+  if (pl.splits > 1) {
+    const size_t total4 = (size_t)M * N / 4;
+    int blocks = (int)((total4 + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, p, pl.splits);
+    DCLIP_CHECK_LAUNCH("gemm_f32.splitk_reduce");
+  }
+  return DCLIP_OK;
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Contrastive loss on top of the same MFMA kernel: the [Bl,Bg] logits are produced tile by tile and reduced
+// to per-row (max, sum-exp) partials in the epilogue — they are never stored.
+namespace {
+
+constexpr int LOSS_BM = 64, LOSS_BN = 64, LOSS_WN = 2;
+
+// one wave per local row: merge the column-tile partials, and compute the positive logit
+__global__ void __launch_bounds__(256) lse_merge_kernel(const float* __restrict__ part_m, const float* __restrict__ part_s,
+                                                        const float* __restrict__ a, const float* __restrict__ b,
+                                                        float* __restrict__ lse, float* __restrict__ diag, int Bl, int Bg,
+                                                        int P, int nslots, int offset, float inv_temp) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= Bl) return;
+  float m = -INFINITY;
+  for (int s = lane; s < nslots; s += 64) m = fmaxf(m, part_m[(size_t)s * Bl + row]);
+  m = wave_max(m);
+  float sum = 0.f;
+  for (int s = lane; s < nslots; s += 64) sum += part_s[(size_t)s * Bl + row] * __expf(part_m[(size_t)s * Bl + row] - m);
+  sum = wave_sum(sum);
+  float d = 0.f;
+  const int col = row + offset;
+  if (col >= 0 && col < Bg)
+    for (int k = lane; k < P; k += 64) d += a[(size_t)row * P + k] * b[(size_t)col * P + k];
+  d = wave_sum(d);
+  if (lane == 0) {
+    lse[row] = m + __logf(sum);
+    diag[row] = d * inv_temp;
+  }
+}
+
+size_t loss_slots(int Bg) { return (size_t)cdiv(Bg, LOSS_BN) * LOSS_WN; }
+
+}  // namespace
+
+DCLIP_API size_t dclip_contrastive_workspace(int Bl, int Bg, int P) {
+  (void)P;
+  size_t lse_bytes = 2 * loss_slots(Bg) * (size_t)Bl * sizeof(float);
+  size_t dz_bytes = (size_t)Bl * ((Bg + 3) / 4 * 4) * sizeof(float);
+  return lse_bytes > dz_bytes ? lse_bytes : dz_bytes;
+}
+
+DCLIP_API int dclip_contrastive_lse(const float* a_local, const float* b_global, float* lse, float* diag, int Bl, int Bg,
+                                    int P, int offset, float inv_temp, void* workspace, size_t workspace_bytes,
+                                    void* stream) {
+  DCLIP_REQUIRE(a_local && b_global && lse && diag, "contrastive_lse: null pointer");
+  DCLIP_REQUIRE(Bl > 0 && Bg > 0 && P > 0 && P % 4 == 0, "contrastive_lse: bad shape Bl=%d Bg=%d P=%d", Bl, Bg, P);
+  const size_t slots = loss_slots(Bg);
+  if (!workspace || workspace_bytes < 2 * slots * Bl * sizeof(float)) {
+    dclip_set_error("contrastive_lse: workspace too small");
+    return DCLIP_EWORKSPACE;
+  }
+  float* pm = (float*)workspace;
+  float* ps = pm + slots * Bl;
+  GemmParams p{a_local, b_global, nullptr, nullptr, nullptr, nullptr, Bl, Bg, P, P, P, 0, 0, inv_temp,
+               cdiv(Bl, LOSS_BM), cdiv(Bg, LOSS_BN), cdiv(P, BK) * BK, nullptr,
+               MODE_LSE, nullptr, nullptr, pm, ps, offset};
+  hipStream_t st = (hipStream_t)stream;
+  launch_cfg<LOSS_BM, LOSS_BN, 2, LOSS_WN>(p, DCLIP_A_KMAJOR | DCLIP_B_KMAJOR, 1, st);
+  DCLIP_CHECK_LAUNCH("contrastive_lse");
+  hipLaunchKernelGGL(lse_merge_kernel, dim3(cdiv(Bl, 4)), dim3(256), 0, st, pm, ps, a_local, b_global, lse, diag, Bl, Bg, P,
+                     (int)slots, offset, inv_temp);
+  DCLIP_CHECK_LAUNCH("contrastive_lse.merge");
+  return DCLIP_OK;
+}
+
+DCLIP_API int dclip_contrastive_grad(const float* a_local, const float* b_global, const float* lse_row,
+                                     const float* lse_col, float* da_local, int Bl, int Bg, int P, int offset,
+                                     float inv_temp, float coef, void* workspace, size_t workspace_bytes, void* stream) {
+  DCLIP_REQUIRE(a_local && b_global && lse_row && lse_col && da_local, "contrastive_grad: null pointer");
+  DCLIP_REQUIRE(Bl > 0 && Bg > 0 && P > 0 && P % 4 == 0, "contrastive_grad: bad shape");
+  const int ldw = (Bg + 3) / 4 * 4;
+  if (!workspace || workspace_bytes < (size_t)Bl * ldw * sizeof(float)) {
+    dclip_set_error("contrastive_grad: workspace too small");
+    return DCLIP_EWORKSPACE;
+  }
+  float* W = (float*)workspace;
+  hipStream_t st = (hipStream_t)stream;
+  // W[i,j] = exp(z_ij - lse_row[i]) + exp(z_ij - lse_col[j]) - 2[j == i+offset]
+  GemmParams p{a_local, b_global, W, nullptr, nullptr, nullptr, Bl, Bg, P, P, P, ldw, 0, inv_temp,
+               cdiv(Bl, LOSS_BM), cdiv(Bg, LOSS_BN), cdiv(P, BK) * BK, nullptr,
+               MODE_DZ, lse_row, lse_col, nullptr, nullptr, offset};
+  launch_cfg<LOSS_BM, LOSS_BN, 2, LOSS_WN>(p, DCLIP_A_KMAJOR | DCLIP_B_KMAJOR, 1, st);
+  DCLIP_CHECK_LAUNCH("contrastive_grad.dz");
+  // da = coef * W[Bl,Bg] * b_global[Bg,P]   (K = Bg may be ragged; lda = ldw keeps rows 16-byte aligned)
+  return dclip_gemm_f32(W, b_global, da_local, nullptr, nullptr, nullptr, Bl, P, Bg, ldw, P, P, DCLIP_A_KMAJOR, 0, coef, 1,
+                        nullptr, 0, stream);
+}

@@ -1,0 +1,250 @@
+// LayerNorm forward / backward and column sums (HBM-bound; one wave per row, 16-byte accesses).
+//
+// Algorithmic bytes: fwd reads x and writes y (8 B/element); bwd reads dy, x (+dresidual) and writes dx
+// (12-16 B/element).  Row statistics are two-pass in registers (mean, then centred variance), like ATen.
+#include "common.h"
+
+namespace {
+
+constexpr int MAXC = 8;  // float4 chunks per lane -> D <= 2048
+
+template <int NC>
+__global__ void __launch_bounds__(256) ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, float* __restrict__ y,
+                                                     float* __restrict__ mean, float* __restrict__ rstd, int rows,
+                                                     int D, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int d4 = D >> 2;
+  const f32x4* xr = reinterpret_cast<const f32x4*>(x + (size_t)row * D);
+  f32x4 v[NC];
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    int i = lane + 64 * c;
+    v[c] = (i < d4) ? xr[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+    s += (v[c][0] + v[c][1]) + (v[c][2] + v[c][3]);
+  }
+  const float mu = wave_sum(s) / (float)D;
+  float q = 0.f;
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    int i = lane + 64 * c;
+    if (i < d4) {
+      f32x4 d = v[c] - mu;
+      q += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+    }
+  }
+  const float rs = rsqrtf(wave_sum(q) / (float)D + eps);
+  if (lane == 0) {
+    if (mean) mean[row] = mu;
+    if (rstd) rstd[row] = rs;
+  }
+  f32x4* yr = reinterpret_cast<f32x4*>(y + (size_t)row * D);
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    int i = lane + 64 * c;
+    if (i < d4) {
+      f32x4 g = reinterpret_cast<const f32x4*>(gamma)[i];
+      f32x4 b = reinterpret_cast<const f32x4*>(beta)[i];
+      yr[i] = (v[c] - mu) * rs * g + b;
+    }
+  }
+}
+
+// Each wave walks rows with a grid stride; per-column dgamma/dbeta partials stay in registers, are summed
+// over the block's 4 waves through LDS and written to partial[blockIdx][2][D].
+template <int NC>
+__global__ void __launch_bounds__(256) ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                     const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                     const float* __restrict__ rstd, const float* __restrict__ dres,
+                                                     float* __restrict__ dx, float* __restrict__ partial, int rows,
+                                                     int D) {
+  extern __shared__ __attribute__((aligned(16))) float red[];  // [4][2][D]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int d4 = D >> 2;
+  f32x4 g[NC], dg[NC], db[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    int i = lane + 64 * c;
+    g[c] = (i < d4) ? reinterpret_cast<const f32x4*>(gamma)[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+    dg[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    db[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const float invD = 1.0f / (float)D;
+  for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
+    const f32x4* xr = reinterpret_cast<const f32x4*>(x + (size_t)row * D);
+    const f32x4* dyr = reinterpret_cast<const f32x4*>(dy + (size_t)row * D);
+    const float mu = mean[row], rs = rstd[row];
+    f32x4 xh[NC], dyh[NC];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      int i = lane + 64 * c;
+      if (i < d4) {
+        f32x4 dyv = dyr[i];
+        xh[c] = (xr[i] - mu) * rs;
+        dg[c] += dyv * xh[c];
+        db[c] += dyv;
+        dyh[c] = dyv * g[c];
+        f32x4 t = dyh[c] * xh[c];
+        s1 += (t[0] + t[1]) + (t[2] + t[3]);
+        s2 += (dyh[c][0] + dyh[c][1]) + (dyh[c][2] + dyh[c][3]);
+      } else {
+        xh[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        dyh[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+    const float c1 = wave_sum(s1) * invD, c2 = wave_sum(s2) * invD;
+    f32x4* dxr = reinterpret_cast<f32x4*>(dx + (size_t)row * D);
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      int i = lane + 64 * c;
+      if (i < d4) {
+        f32x4 o = (dyh[c] - c2 - xh[c] * c1) * rs;
+        if (dres) o += reinterpret_cast<const f32x4*>(dres + (size_t)row * D)[i];
+        dxr[i] = o;
+      }
+    }
+  }
+  if (partial) {
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      int i = lane + 64 * c;
+      if (i < d4) {
+        reinterpret_cast<f32x4*>(red + (wave * 2 + 0) * D)[i] = dg[c];
+        reinterpret_cast<f32x4*>(red + (wave * 2 + 1) * D)[i] = db[c];
+      }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * D; i += 256) {
+      float s = red[i] + red[2 * D + i] + red[4 * D + i] + red[6 * D + i];
+      partial[(size_t)blockIdx.x * 2 * D + i] = s;
+    }
+  }
+}
+
+// out[n] (+)= sum_p partial[p][n]   (fixed order -> deterministic)
+__global__ void __launch_bounds__(256) reduce_partials_kernel(const float* __restrict__ partial, float* __restrict__ out0,
+                                                              float* __restrict__ out1, int P, int N0, int N1,
+                                                              int accumulate) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  const int N = N0 + N1;
+  if (n >= N) return;
+  float s = 0.f;
+  for (int p = 0; p < P; ++p) s += partial[(size_t)p * N + n];
+  float* base = (n < N0) ? out0 : out1;
+  if (!base) return;
+  float* o = base + ((n < N0) ? n : n - N0);
+  *o = accumulate ? *o + s : s;
+}
+
+// column sums: block = 64 float4-columns x 4 row lanes; grid.y splits the rows
+__global__ void __launch_bounds__(256) colsum_kernel(const float* __restrict__ X, float* __restrict__ partial, int M,
+                                                     int N, int ldx) {
+  __shared__ f32x4 red[4][64];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c4 = blockIdx.x * 64 + cl;
+  const int n4 = N >> 2;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  if (c4 < n4) {
+    const int rows_per = (M + gridDim.y - 1) / gridDim.y;
+    const int r0 = blockIdx.y * rows_per, r1 = min(M, r0 + rows_per);
+    for (int r = r0 + rl; r < r1; r += 4) s += *reinterpret_cast<const f32x4*>(X + (size_t)r * ldx + c4 * 4);
+  }
+  red[rl][cl] = s;
+  __syncthreads();
+  if (rl == 0 && c4 < n4) {
+    f32x4 t = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
+    *reinterpret_cast<f32x4*>(partial + (size_t)blockIdx.y * N + c4 * 4) = t;
+  }
+}
+
+inline int ln_bwd_blocks(int rows) {
+  int b = cdiv(rows, 4);
+  return b > 512 ? 512 : b;
+}
+inline int colsum_splits(int M) {
+  int s = cdiv(M, 64);
+  return s > 128 ? 128 : (s < 1 ? 1 : s);
+}
+
+}  // namespace
+
+DCLIP_API int dclip_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean,
+                                  float* rstd, int rows, int D, float eps, void* stream) {
+  DCLIP_REQUIRE(x && gamma && beta && y, "layernorm_fwd: null pointer");
+  DCLIP_REQUIRE(rows > 0 && D > 0 && D % 4 == 0 && D <= 256 * MAXC, "layernorm_fwd: D=%d must be a multiple of 4, <= %d",
+                D, 256 * MAXC);
+  dim3 grid(cdiv(rows, 4)), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  const int nc = cdiv(D / 4, 64);
+#define LN_FWD(NC) hipLaunchKernelGGL((ln_fwd_kernel<NC>), grid, block, 0, st, x, gamma, beta, y, mean, rstd, rows, D, eps)
+  if (nc <= 1) LN_FWD(1);
+  else if (nc == 2) LN_FWD(2);
+  else if (nc == 3) LN_FWD(3);
+  else if (nc == 4) LN_FWD(4);
+  else LN_FWD(8);
+#undef LN_FWD
+  DCLIP_CHECK_LAUNCH("layernorm_fwd");
+  return DCLIP_OK;
+}
+
+DCLIP_API size_t dclip_layernorm_bwd_workspace(int rows, int D) {
+  return (size_t)ln_bwd_blocks(rows) * 2 * D * sizeof(float);
+}
+
+DCLIP_API int dclip_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean,
+                                  const float* rstd, const float* dresidual, float* dx, float* dgamma,
+                                  float* dbeta, int rows, int D, int accumulate_param_grads, void* workspace,
+                                  size_t workspace_bytes, void* stream) {
+  DCLIP_REQUIRE(dy && x && gamma && mean && rstd && dx, "layernorm_bwd: null pointer");
+  DCLIP_REQUIRE(rows > 0 && D > 0 && D % 4 == 0 && D <= 256 * MAXC, "layernorm_bwd: bad D=%d", D);
+  const bool want_params = dgamma || dbeta;
+  const int blocks = ln_bwd_blocks(rows);
+  if (want_params && (!workspace || workspace_bytes < dclip_layernorm_bwd_workspace(rows, D))) {
+    dclip_set_error("layernorm_bwd: workspace too small (%zu < %zu)", workspace_bytes,
+                    dclip_layernorm_bwd_workspace(rows, D));
+    return DCLIP_EWORKSPACE;
+  }
+  float* partial = want_params ? (float*)workspace : nullptr;
+  hipStream_t st = (hipStream_t)stream;
+  const size_t lds = want_params ? (size_t)8 * D * sizeof(float) : 0;
+  const int nc = cdiv(D / 4, 64);
+#define LN_BWD(NC) \
+  hipLaunchKernelGGL((ln_bwd_kernel<NC>), dim3(blocks), dim3(256), lds, st, dy, x, gamma, mean, rstd, dresidual, dx, partial, rows, D)
+  if (nc <= 1) LN_BWD(1);
+  else if (nc == 2) LN_BWD(2);
+  else if (nc == 3) LN_BWD(3);
+  else if (nc == 4) LN_BWD(4);
+  else LN_BWD(8);
+#undef LN_BWD
+  DCLIP_CHECK_LAUNCH("layernorm_bwd");
+  if (want_params) {
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(2 * D, 256)), dim3(256), 0, st, partial, dgamma, dbeta, blocks, D,
+                       D, accumulate_param_grads);
+    DCLIP_CHECK_LAUNCH("layernorm_bwd.reduce");
+  }
+  return DCLIP_OK;
+}
+
+DCLIP_API size_t dclip_colsum_f32_workspace(int M, int N) { return (size_t)colsum_splits(M) * N * sizeof(float); }
+
+DCLIP_API int dclip_colsum_f32(const float* X, float* out, int M, int N, int ldx, int accumulate, void* workspace,
+                               size_t workspace_bytes, void* stream) {
+  DCLIP_REQUIRE(X && out, "colsum: null pointer");
+  DCLIP_REQUIRE(M > 0 && N > 0 && N % 4 == 0 && ldx % 4 == 0 && ldx >= N, "colsum: bad shape M=%d N=%d ldx=%d", M, N, ldx);
+  const int splits = colsum_splits(M);
+  if (!workspace || workspace_bytes < (size_t)splits * N * sizeof(float)) {
+    dclip_set_error("colsum: workspace too small");
+    return DCLIP_EWORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(N / 4, 64), splits), dim3(256), 0, st, X, (float*)workspace, M, N, ldx);
+  DCLIP_CHECK_LAUNCH("colsum");
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(N, 256)), dim3(256), 0, st, (const float*)workspace, out,
+                     (float*)nullptr, splits, N, 0, accumulate);
+  DCLIP_CHECK_LAUNCH("colsum.reduce");
+  return DCLIP_OK;
+}

@@ -1,0 +1,407 @@
+"""Tensor-level wrappers over the C ABI (no autograd here; see functional.py).
+
+PyTorch is plumbing only: it owns device memory and the HIP stream.  Every wrapper checks
+device / dtype / contiguity on the host before a kernel sees a pointer — a faulting kernel
+can reset the whole GPU host (shape checks are cheap, resets are not).
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import _lib
+
+A_KMAJOR, B_KMAJOR = 1, 2
+EPI_BIAS, EPI_GELU, EPI_DGELU, EPI_RESIDUAL, EPI_ACCUM = 1, 2, 4, 8, 16
+LAYOUT_NT = A_KMAJOR | B_KMAJOR     # y = x W^T
+LAYOUT_NN = A_KMAJOR                # dx = dy W
+LAYOUT_TN = 0                       # dW = dy^T x
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _f32(t: torch.Tensor, name: str) -> torch.Tensor:
+    if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+        raise ValueError(f"{name}: expected a contiguous float32 CUDA tensor, got {t.dtype} {t.device} "
+                         f"contiguous={t.is_contiguous()}")
+    return t
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+class _Workspace:
+    """Grow-only scratch buffer per device (the library never allocates)."""
+
+    def __init__(self):
+        self.buf = {}
+
+    def get(self, nbytes: int, device) -> Optional[torch.Tensor]:
+        if nbytes == 0:
+            return None
+        key = (device.index, torch.cuda.current_stream().cuda_stream)
+        b = self.buf.get(key)
+        if b is None or b.numel() < nbytes:
+            b = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+            self.buf[key] = b
+        return b
+
+
+_ws = _Workspace()
+
+
+# ------------------------------------------------------------------------------------------- GEMM
+
+def gemm(a: torch.Tensor, b: torch.Tensor, layout: int, *, out: Optional[torch.Tensor] = None,
+         bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
+         aux: Optional[torch.Tensor] = None, epilogue: int = 0, alpha: float = 1.0, split_k: int = 0
+         ) -> torch.Tensor:
+    """C = epilogue(alpha * op(a) @ op(b)); see include/dclip_hip.h for layout / epilogue bits."""
+    lib = _lib.load()
+    _f32(a, "a"), _f32(b, "b")
+    if a.dim() != 2 or b.dim() != 2:
+        raise ValueError("gemm: 2-D operands")
+    if layout & A_KMAJOR:
+        M, K = a.shape
+    else:
+        K, M = a.shape
+    if layout & B_KMAJOR:
+        N, Kb = b.shape
+    else:
+        Kb, N = b.shape
+    if K != Kb:
+        raise ValueError(f"gemm: contraction mismatch {tuple(a.shape)} x {tuple(b.shape)} layout={layout}")
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    _f32(out, "out")
+    if tuple(out.shape) != (M, N):
+        raise ValueError(f"gemm: out shape {tuple(out.shape)} != {(M, N)}")
+    if bias is not None:
+        epilogue |= EPI_BIAS
+        if _f32(bias, "bias").numel() != N:
+            raise ValueError("gemm: bias size")
+    if residual is not None:
+        epilogue |= EPI_RESIDUAL
+        if tuple(_f32(residual, "residual").shape) != (M, N):
+            raise ValueError("gemm: residual shape")
+    if aux is not None and tuple(_f32(aux, "aux").shape) != (M, N):
+        raise ValueError("gemm: aux shape")
+    nbytes = lib.dclip_gemm_f32_workspace(M, N, K, layout, split_k)
+    ws = _ws.get(nbytes, a.device)
+    _lib.check(lib.dclip_gemm_f32(a.data_ptr(), b.data_ptr(), out.data_ptr(), _ptr(bias), _ptr(residual),
+                                  _ptr(aux), M, N, K, a.shape[1], b.shape[1], N, layout, epilogue,
+                                  float(alpha), split_k, _ptr(ws), nbytes, _stream()), "gemm_f32")
+    return out
+
+
+def colsum(x: torch.Tensor, out: Optional[torch.Tensor] = None, accumulate: bool = False) -> torch.Tensor:
+    lib = _lib.load()
+    _f32(x, "x")
+    M, N = x.shape
+    if out is None:
+        out = torch.empty((N,), dtype=torch.float32, device=x.device)
+        accumulate = False
+    _f32(out, "out")
+    if out.numel() != N:
+        raise ValueError("colsum: out size")
+    nbytes = lib.dclip_colsum_f32_workspace(M, N)
+    ws = _ws.get(nbytes, x.device)
+    _lib.check(lib.dclip_colsum_f32(x.data_ptr(), out.data_ptr(), M, N, N, int(accumulate), _ptr(ws), nbytes,
+                                    _stream()), "colsum")
+    return out
+
+
+# ------------------------------------------------------------------------------------------- LayerNorm
+
+def layernorm_fwd(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float, save_stats: bool = True):
+    lib = _lib.load()
+    _f32(x, "x"), _f32(gamma, "gamma"), _f32(beta, "beta")
+    D = x.shape[-1]
+    rows = x.numel() // D
+    if gamma.numel() != D or beta.numel() != D:
+        raise ValueError("layernorm: gamma/beta size")
+    y = torch.empty_like(x)
+    mean = torch.empty((rows,), dtype=torch.float32, device=x.device) if save_stats else None
+    rstd = torch.empty((rows,), dtype=torch.float32, device=x.device) if save_stats else None
+    _lib.check(lib.dclip_layernorm_fwd(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), _ptr(mean),
+                                       _ptr(rstd), rows, D, float(eps), _stream()), "layernorm_fwd")
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy, x, gamma, mean, rstd, *, dresidual=None, dgamma=None, dbeta=None, accumulate=False,
+                  need_param_grads=True):
+    """Returns (dx, dgamma, dbeta); dgamma/dbeta are written (or accumulated into) if requested."""
+    lib = _lib.load()
+    _f32(dy, "dy"), _f32(x, "x"), _f32(gamma, "gamma"), _f32(mean, "mean"), _f32(rstd, "rstd")
+    D = x.shape[-1]
+    rows = x.numel() // D
+    if dy.shape != x.shape or mean.numel() != rows or rstd.numel() != rows or gamma.numel() != D:
+        raise ValueError("layernorm_bwd: shape mismatch")
+    if dresidual is not None and _f32(dresidual, "dresidual").shape != x.shape:
+        raise ValueError("layernorm_bwd: dresidual shape")
+    dx = torch.empty_like(x)
+    if need_param_grads:
+        if dgamma is None:
+            dgamma = torch.empty_like(gamma)
+            dbeta = torch.empty_like(gamma)
+            accumulate = False
+        _f32(dgamma, "dgamma"), _f32(dbeta, "dbeta")
+        if dgamma.numel() != D or dbeta.numel() != D:
+            raise ValueError("layernorm_bwd: dgamma/dbeta size")
+    else:
+        dgamma = dbeta = None
+    nbytes = lib.dclip_layernorm_bwd_workspace(rows, D) if need_param_grads else 0
+    ws = _ws.get(nbytes, x.device)
+    _lib.check(lib.dclip_layernorm_bwd(dy.data_ptr(), x.data_ptr(), gamma.data_ptr(), mean.data_ptr(),
+                                       rstd.data_ptr(), _ptr(dresidual), dx.data_ptr(), _ptr(dgamma), _ptr(dbeta),
+                                       rows, D, int(accumulate), _ptr(ws), nbytes, _stream()), "layernorm_bwd")
+    return dx, dgamma, dbeta
+
+
+# ------------------------------------------------------------------------------------------- attention
+
+def attention_fwd(qkv: torch.Tensor, B: int, S: int, H: int, causal: bool):
+    lib = _lib.load()
+    _f32(qkv, "qkv")
+    if qkv.numel() != B * S * 3 * H * 64:
+        raise ValueError(f"attention_fwd: qkv has {qkv.numel()} elements, expected B*S*3*H*64 = {B * S * 3 * H * 64}")
+    out = torch.empty((B * S, H * 64), dtype=torch.float32, device=qkv.device)
+    lse = torch.empty((B, H, S), dtype=torch.float32, device=qkv.device)
+    _lib.check(lib.dclip_attention_fwd(qkv.data_ptr(), out.data_ptr(), lse.data_ptr(), B, S, H, int(causal),
+                                       _stream()), "attention_fwd")
+    return out, lse
+
+
+def attention_bwd(qkv, out, dout, lse, B: int, S: int, H: int, causal: bool):
+    lib = _lib.load()
+    _f32(qkv, "qkv"), _f32(out, "out"), _f32(dout, "dout"), _f32(lse, "lse")
+    if qkv.numel() != B * S * 3 * H * 64 or out.numel() != B * S * H * 64 or dout.numel() != out.numel() \
+            or lse.numel() != B * H * S:
+        raise ValueError("attention_bwd: shape mismatch")
+    dqkv = torch.empty_like(qkv)
+    delta = torch.empty((B * H * S,), dtype=torch.float32, device=qkv.device)
+    _lib.check(lib.dclip_attention_bwd(qkv.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(),
+                                       dqkv.data_ptr(), delta.data_ptr(), B, S, H, int(causal), _stream()),
+               "attention_bwd")
+    return dqkv
+
+
+# ------------------------------------------------------------------------------------------- embeddings
+
+def im2col(pixels: torch.Tensor, patch: int) -> torch.Tensor:
+    lib = _lib.load()
+    _f32(pixels, "pixel_values")
+    B, Cc, Hh, Ww = pixels.shape
+    if Hh != Ww or Hh % patch:
+        raise ValueError(f"im2col: image {Hh}x{Ww} not a multiple of patch {patch}")
+    g = Hh // patch
+    cols = torch.empty((B * g * g, Cc * patch * patch), dtype=torch.float32, device=pixels.device)
+    _lib.check(lib.dclip_im2col(pixels.data_ptr(), cols.data_ptr(), B, Cc, Hh, Ww, patch, _stream()), "im2col")
+    return cols
+
+
+def vision_assemble_fwd(patch_emb, cls, pos, B: int, S: int, D: int) -> torch.Tensor:
+    lib = _lib.load()
+    _f32(patch_emb, "patch_emb"), _f32(cls, "class_embedding"), _f32(pos, "position_embedding")
+    if patch_emb.numel() != B * (S - 1) * D or cls.numel() != D or pos.numel() != S * D:
+        raise ValueError("vision_assemble_fwd: shape mismatch")
+    x = torch.empty((B * S, D), dtype=torch.float32, device=patch_emb.device)
+    _lib.check(lib.dclip_vision_assemble_fwd(patch_emb.data_ptr(), cls.data_ptr(), pos.data_ptr(), x.data_ptr(),
+                                             B, S, D, _stream()), "vision_assemble_fwd")
+    return x
+
+
+def vision_assemble_bwd(dx, B: int, S: int, D: int) -> torch.Tensor:
+    lib = _lib.load()
+    _f32(dx, "dx")
+    if dx.numel() != B * S * D:
+        raise ValueError("vision_assemble_bwd: shape mismatch")
+    dpatch = torch.empty((B * (S - 1), D), dtype=torch.float32, device=dx.device)
+    _lib.check(lib.dclip_vision_assemble_bwd(dx.data_ptr(), dpatch.data_ptr(), B, S, D, _stream()),
+               "vision_assemble_bwd")
+    return dpatch
+
+
+def _ids(ids: torch.Tensor) -> torch.Tensor:
+    if not (ids.is_cuda and ids.dtype == torch.int64 and ids.is_contiguous() and ids.dim() == 2):
+        raise ValueError("input_ids: expected a contiguous int64 CUDA tensor [B, T]")
+    return ids
+
+
+def text_embed_fwd(ids, tok, pos) -> torch.Tensor:
+    lib = _lib.load()
+    _ids(ids), _f32(tok, "token_embedding"), _f32(pos, "position_embedding")
+    B, T = ids.shape
+    vocab, D = tok.shape
+    if pos.shape[0] < T or pos.shape[1] != D:
+        raise ValueError(f"text_embed_fwd: sequence {T} longer than position table {tuple(pos.shape)}")
+    x = torch.empty((B * T, D), dtype=torch.float32, device=tok.device)
+    _lib.check(lib.dclip_text_embed_fwd(ids.data_ptr(), tok.data_ptr(), pos.data_ptr(), x.data_ptr(), B, T, D, vocab,
+                                        _stream()), "text_embed_fwd")
+    return x
+
+
+def text_embed_bwd(ids, dx, dtok):
+    lib = _lib.load()
+    _ids(ids), _f32(dx, "dx"), _f32(dtok, "dtok")
+    B, T = ids.shape
+    vocab, D = dtok.shape
+    if dx.numel() != B * T * D:
+        raise ValueError("text_embed_bwd: shape mismatch")
+    _lib.check(lib.dclip_text_embed_bwd(ids.data_ptr(), dx.data_ptr(), dtok.data_ptr(), B, T, D, vocab, _stream()),
+               "text_embed_bwd")
+    return dtok
+
+
+def first_eos(ids, eos_id: int) -> torch.Tensor:
+    lib = _lib.load()
+    _ids(ids)
+    B, T = ids.shape
+    idx = torch.empty((B,), dtype=torch.int32, device=ids.device)
+    _lib.check(lib.dclip_first_eos(ids.data_ptr(), idx.data_ptr(), B, T, int(eos_id), _stream()), "first_eos")
+    return idx
+
+
+def _idx(idx, B):
+    if idx is None:
+        return None
+    if not (idx.is_cuda and idx.dtype == torch.int32 and idx.is_contiguous() and idx.numel() == B):
+        raise ValueError("row index: expected contiguous int32 CUDA tensor [B]")
+    return idx
+
+
+def gather_rows(x, idx, B: int, S: int, D: int) -> torch.Tensor:
+    lib = _lib.load()
+    _f32(x, "x"), _idx(idx, B)
+    if x.numel() != B * S * D:
+        raise ValueError("gather_rows: shape mismatch")
+    out = torch.empty((B, D), dtype=torch.float32, device=x.device)
+    _lib.check(lib.dclip_gather_rows(x.data_ptr(), _ptr(idx), out.data_ptr(), B, S, D, _stream()), "gather_rows")
+    return out
+
+
+def scatter_rows(dout, idx, B: int, S: int, D: int) -> torch.Tensor:
+    lib = _lib.load()
+    _f32(dout, "dout"), _idx(idx, B)
+    if dout.numel() != B * D:
+        raise ValueError("scatter_rows: shape mismatch")
+    dx = torch.empty((B * S, D), dtype=torch.float32, device=dout.device)
+    _lib.check(lib.dclip_scatter_rows(dout.data_ptr(), _ptr(idx), dx.data_ptr(), B, S, D, _stream()), "scatter_rows")
+    return dx
+
+
+# ------------------------------------------------------------------------------------------- losses
+
+NORM_EPS = 1e-12
+
+
+def normalize_rows_fwd(x):
+    lib = _lib.load()
+    _f32(x, "x")
+    B, Pd = x.shape
+    xhat = torch.empty_like(x)
+    inv = torch.empty((B,), dtype=torch.float32, device=x.device)
+    _lib.check(lib.dclip_normalize_rows_fwd(x.data_ptr(), xhat.data_ptr(), inv.data_ptr(), B, Pd, NORM_EPS, _stream()),
+               "normalize_rows_fwd")
+    return xhat, inv
+
+
+def normalize_rows_bwd(dxhat, xhat, inv, dx=None, accumulate=False):
+    lib = _lib.load()
+    _f32(dxhat, "dxhat"), _f32(xhat, "xhat"), _f32(inv, "inv")
+    B, Pd = xhat.shape
+    if dxhat.shape != xhat.shape or inv.numel() != B:
+        raise ValueError("normalize_rows_bwd: shape mismatch")
+    if dx is None:
+        dx = torch.empty_like(xhat)
+        accumulate = False
+    _f32(dx, "dx")
+    _lib.check(lib.dclip_normalize_rows_bwd(dxhat.data_ptr(), xhat.data_ptr(), inv.data_ptr(), dx.data_ptr(), B, Pd,
+                                            NORM_EPS, int(accumulate), _stream()), "normalize_rows_bwd")
+    return dx
+
+
+def contrastive_lse(a_local, b_global, offset: int, inv_temp: float):
+    lib = _lib.load()
+    _f32(a_local, "a_local"), _f32(b_global, "b_global")
+    Bl, Pd = a_local.shape
+    Bg, Pb = b_global.shape
+    if Pd != Pb or not (0 <= offset and offset + Bl <= Bg):
+        raise ValueError(f"contrastive_lse: shapes {tuple(a_local.shape)} {tuple(b_global.shape)} offset {offset}")
+    lse = torch.empty((Bl,), dtype=torch.float32, device=a_local.device)
+    diag = torch.empty((Bl,), dtype=torch.float32, device=a_local.device)
+    nbytes = lib.dclip_contrastive_workspace(Bl, Bg, Pd)
+    ws = _ws.get(nbytes, a_local.device)
+    _lib.check(lib.dclip_contrastive_lse(a_local.data_ptr(), b_global.data_ptr(), lse.data_ptr(), diag.data_ptr(), Bl,
+                                         Bg, Pd, offset, float(inv_temp), _ptr(ws), nbytes, _stream()),
+               "contrastive_lse")
+    return lse, diag
+
+
+def contrastive_grad(a_local, b_global, lse_row, lse_col, offset: int, inv_temp: float, coef: float):
+    lib = _lib.load()
+    _f32(a_local, "a_local"), _f32(b_global, "b_global"), _f32(lse_row, "lse_row"), _f32(lse_col, "lse_col")
+    Bl, Pd = a_local.shape
+    Bg = b_global.shape[0]
+    if lse_row.numel() != Bl or lse_col.numel() != Bg or b_global.shape[1] != Pd:
+        raise ValueError("contrastive_grad: shape mismatch")
+    da = torch.empty_like(a_local)
+    nbytes = lib.dclip_contrastive_workspace(Bl, Bg, Pd)
+    ws = _ws.get(nbytes, a_local.device)
+    _lib.check(lib.dclip_contrastive_grad(a_local.data_ptr(), b_global.data_ptr(), lse_row.data_ptr(),
+                                          lse_col.data_ptr(), da.data_ptr(), Bl, Bg, Pd, offset, float(inv_temp),
+                                          float(coef), _ptr(ws), nbytes, _stream()), "contrastive_grad")
+    return da
+
+
+def cosine_loss_fwd(s, t):
+    lib = _lib.load()
+    _f32(s, "student"), _f32(t, "teacher")
+    if s.shape != t.shape:
+        raise ValueError(f"cosine_distillation_loss: shapes {tuple(s.shape)} vs {tuple(t.shape)} — the reference "
+                         "raises here too (CLIP_image_distillation.py:573)")
+    B, Pd = s.shape
+    loss_sum = torch.empty((), dtype=torch.float32, device=s.device)
+    cos = torch.empty((B,), dtype=torch.float32, device=s.device)
+    _lib.check(lib.dclip_cosine_loss_fwd(s.data_ptr(), t.data_ptr(), loss_sum.data_ptr(), cos.data_ptr(), B, Pd,
+                                         _stream()), "cosine_loss_fwd")
+    return loss_sum, cos
+
+
+def cosine_loss_bwd(s, t, cos, coef: float, ds=None, accumulate=False):
+    lib = _lib.load()
+    _f32(s, "student"), _f32(t, "teacher"), _f32(cos, "cos")
+    B, Pd = s.shape
+    if ds is None:
+        ds = torch.empty_like(s)
+        accumulate = False
+    _lib.check(lib.dclip_cosine_loss_bwd(s.data_ptr(), t.data_ptr(), cos.data_ptr(), ds.data_ptr(), B, Pd, float(coef),
+                                         int(accumulate), _stream()), "cosine_loss_bwd")
+    return ds
+
+
+def sub_reduce(a, b, scale: float, out=None, accumulate=False):
+    lib = _lib.load()
+    _f32(a, "a")
+    if b is not None and _f32(b, "b").numel() != a.numel():
+        raise ValueError("sub_reduce: size mismatch")
+    if out is None:
+        out = torch.empty((), dtype=torch.float32, device=a.device)
+        accumulate = False
+    _lib.check(lib.dclip_sub_reduce(a.data_ptr(), _ptr(b), out.data_ptr(), a.numel(), float(scale), int(accumulate),
+                                    _stream()), "sub_reduce")
+    return out
+
+
+def axpby(x, y, a: float, b: float):
+    """y = a*x + b*y (in place on y)."""
+    lib = _lib.load()
+    _f32(x, "x"), _f32(y, "y")
+    if x.numel() != y.numel():
+        raise ValueError("axpby: size mismatch")
+    _lib.check(lib.dclip_axpby(x.data_ptr(), y.data_ptr(), float(a), float(b), x.numel(), _stream()), "axpby")
+    return y

@@ -1,0 +1,186 @@
+/*
+ * dclip_hip.h — C ABI of libdclip_hip.so: the MI355X (gfx950) kernels behind the DCLIP
+ * distillation step.
+ *
+ * The reference (ChuckDanz/DCLIP) has no FFI of its own: every dense operation on its hot
+ * path is a call into a third-party Python library (HF transformers CLIPModel, torch
+ * nn.MultiheadAttention, torch.nn.functional).  Each entry point below therefore cites the
+ * reference call site (path:line under /root/reference, or hf: for transformers 5.15.0
+ * modeling_clip.py) whose arithmetic it replaces.  The Python binding a maintainer adds is
+ * shown in INTEGRATION.md; the one this repo ships is dclip_amd/_lib.py (ctypes).
+ *
+ * Conventions (all entry points):
+ *   - plain pointers + sizes; every pointer is DEVICE memory owned by the caller (incl.
+ *     `workspace`); the library never allocates, frees or synchronises.
+ *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream);
+ *     work is enqueued on it and the call returns immediately.
+ *   - tensors are row-major, contiguous unless a leading dimension is given; activations are
+ *     [rows = batch*seq, features]; weights are [out, in] exactly as stored in the checkpoints.
+ *   - return 0 on success, negative DCLIP_E* otherwise; dclip_last_error() gives the text of the
+ *     calling thread's last failure.  No exceptions cross the ABI.
+ *   - all arithmetic is IEEE fp32 (exact-f32 MFMA, v_mfma_f32_32x32x2_f32 / 16x16x4_f32).
+ */
+#ifndef DCLIP_HIP_H
+#define DCLIP_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DCLIP_ABI_VERSION 1
+
+enum {
+  DCLIP_OK = 0,
+  DCLIP_EINVAL = -1,      /* bad shape / null pointer / unsupported size */
+  DCLIP_EWORKSPACE = -2,  /* workspace too small */
+  DCLIP_ELAUNCH = -3      /* HIP launch error (text in dclip_last_error) */
+};
+
+int dclip_abi_version(void);
+const char* dclip_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * GEMM  C[M,N] = epilogue( sum_k A(m,k) * B(k,n) )           (fp32 MFMA, LDS-tiled)
+ * Replaces every nn.Linear / Conv2d-as-matmul on the path: q/k/v/out_proj
+ * (hf:modeling_clip.py:309-311,:333), fc1/fc2 (:347-349), patch_embedding (:209),
+ * visual/text_projection (:751,:713), nn.MultiheadAttention in/out projections
+ * (training/patch_text_aggregation.py:33,:42), the logits matmul
+ * (training/CLIP_image_distillation.py:549) and all of their autograd transposes.
+ *
+ * layout bits say which index is contiguous in memory:
+ *   DCLIP_A_KMAJOR : A stored [M][K] (lda >= K), else stored [K][M] (lda >= M)
+ *   DCLIP_B_KMAJOR : B stored [N][K] (ldb >= K, the nn.Linear weight layout), else [K][N]
+ * so  forward  y = x W^T      -> A_KMAJOR | B_KMAJOR
+ *     dgrad    dx = dy W      -> A_KMAJOR            (B = W read as [K=N_out][N=in])
+ *     wgrad    dW = dy^T x    -> 0                   (A = dy as [K=rows][M=out], B = x as [K=rows][N=in])
+ * The contiguous dimension of each operand, and ldc, must be multiples of 4 (16-byte vectors).
+ *
+ * epilogue bits (applied in this order to v = acc * alpha):
+ *   BIAS      v += bias[n]
+ *   GELU      if (aux) aux[m,n] = v;  v = v * sigmoid(1.702 v)        (hf:activations.py:122)
+ *   DGELU     v *= d/dx quick_gelu (aux[m,n])                          (its backward)
+ *   RESIDUAL  v += residual[m,n]   (same ld as C)
+ *   ACCUM     C[m,n] += v  instead of  C[m,n] = v
+ * split_k > 1 partitions K over split_k workgroups per tile; partial tiles go to `workspace`
+ * (dclip_gemm_f32_workspace bytes) and are summed in fixed order by a second launch, so the
+ * result is run-to-run deterministic.  split_k == 0 lets the library choose.
+ */
+#define DCLIP_A_KMAJOR 1
+#define DCLIP_B_KMAJOR 2
+
+#define DCLIP_EPI_BIAS 1
+#define DCLIP_EPI_GELU 2
+#define DCLIP_EPI_DGELU 4
+#define DCLIP_EPI_RESIDUAL 8
+#define DCLIP_EPI_ACCUM 16
+
+size_t dclip_gemm_f32_workspace(int M, int N, int K, int layout, int split_k);
+int dclip_gemm_f32(const float* A, const float* B, float* C, const float* bias, const float* residual,
+                   float* aux, int M, int N, int K, int lda, int ldb, int ldc, int layout, int epilogue,
+                   float alpha, int split_k, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Column sums  out[n] (+)= sum_m X[m,n]  — bias gradients of every nn.Linear above. */
+size_t dclip_colsum_f32_workspace(int M, int N);
+int dclip_colsum_f32(const float* X, float* out, int M, int N, int ldx, int accumulate, void* workspace,
+                     size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * LayerNorm over the last dim (biased variance, eps inside the sqrt) — nn.LayerNorm at
+ * hf:modeling_clip.py:364-366 (layer_norm1/2), :642 (pre_layrnorm), :651 (post_layernorm),
+ * :568 (final_layer_norm); training/patch_text_aggregation.py:35,:44 (norm_text/norm_image).
+ * fwd saves mean and rstd per row.  bwd: dx = LN'(dy) (+ dresidual if non-null: the skip
+ * connection's gradient is added in the same pass); dgamma/dbeta (+)= column reductions.
+ */
+int dclip_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean,
+                        float* rstd, int rows, int D, float eps, void* stream);
+size_t dclip_layernorm_bwd_workspace(int rows, int D);
+int dclip_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean,
+                        const float* rstd, const float* dresidual, float* dx, float* dgamma, float* dbeta,
+                        int rows, int D, int accumulate_param_grads, void* workspace, size_t workspace_bytes,
+                        void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Multi-head self-attention core, head_dim = 64:  O = softmax(Q K^T / 8 [+ causal]) V
+ * — eager_attention_forward, hf:modeling_clip.py:259-277 (vision: no mask; text: causal,
+ * :546-551).  qkv is the fused projection output [B*S, 3*H*64] = [q | k | v] per token;
+ * out is [B*S, H*64]; lse [B, H, S] keeps log-sum-exp per query row for the backward, which
+ * recomputes P instead of storing it.
+ */
+int dclip_attention_fwd(const float* qkv, float* out, float* lse, int B, int S, int H, int causal,
+                        void* stream);
+int dclip_attention_bwd(const float* qkv, const float* out, const float* dout, const float* lse,
+                        float* dqkv, float* delta /* scratch [B*H*S] */, int B, int S, int H, int causal,
+                        void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Embedding plumbing.
+ * im2col: pixel_values [B,C,Himg,Wimg] -> patch rows [B*g*g, C*p*p] so that
+ *   patch_embedding (Conv2d stride=p, no bias; hf:modeling_clip.py:209-210) is one GEMM.
+ * vision_assemble: x[b,0,:] = class_embedding + pos[0]; x[b,1+i,:] = patch[b,i,:] + pos[1+i]
+ *   (hf:modeling_clip.py:212-217).  _bwd copies d x[:,1:,:] into compact d patch rows; d pos is the
+ *   column sum of d x viewed as [B, S*D] (dclip_colsum_f32) and d class is its first D entries.
+ * text_embed: x[b,t,:] = token_embedding[ids[b,t]] + position_embedding[t] (hf:modeling_clip.py:250-255);
+ *   _bwd scatter-adds d x into d token_embedding (float atomics; caller zeroes or accumulates).
+ * first_eos: index of the first EOS id per row, 0 if absent (hf:modeling_clip.py:574-581).
+ * gather_rows: out[b,:] = x[b, idx[b], :] (idx == NULL: row 0, the CLS token, hf:modeling_clip.py:650);
+ * scatter_rows: its transpose, writing the whole [B,S,D] gradient (zeros off the selected row).
+ */
+int dclip_im2col(const float* pixels, float* cols, int B, int C, int Himg, int Wimg, int patch, void* stream);
+int dclip_vision_assemble_fwd(const float* patch, const float* cls, const float* pos, float* x, int B, int S,
+                              int D, void* stream);
+int dclip_vision_assemble_bwd(const float* dx, float* dpatch, int B, int S, int D, void* stream);
+int dclip_text_embed_fwd(const int64_t* ids, const float* tok, const float* pos, float* x, int B, int T, int D,
+                         int vocab, void* stream);
+int dclip_text_embed_bwd(const int64_t* ids, const float* dx, float* dtok, int B, int T, int D, int vocab,
+                         void* stream);
+int dclip_first_eos(const int64_t* ids, int32_t* idx, int B, int T, int64_t eos_id, void* stream);
+int dclip_gather_rows(const float* x, const int32_t* idx, float* out, int B, int S, int D, void* stream);
+int dclip_scatter_rows(const float* dout, const int32_t* idx, float* dx, int B, int S, int D, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Losses.
+ * normalize_rows: xhat = x / max(||x||, eps), inv[b] = 1/max(||x||,eps)   (F.normalize,
+ *   training/CLIP_image_distillation.py:545-546,:569-570; eps = 1e-12).
+ *   _bwd: dx = inv * (dxhat - xhat <dxhat, xhat>); rows where the clamp was active get dxhat/eps.
+ * contrastive_lse: for local rows a_i (i < Bl) against ALL columns b_j (j < Bg), both already
+ *   normalised:  lse[i] = log sum_j exp(<a_i,b_j> * inv_temp),  diag[i] = <a_i, b_{i+offset}> * inv_temp.
+ *   The [Bl,Bg] logits never reach HBM: MFMA tiles are reduced to per-row (max, sum-exp) partials with
+ *   wave shuffles in the GEMM epilogue (training/CLIP_image_distillation.py:549,:556-557).
+ * contrastive_grad: da_i = coef * sum_j ( exp(z_ij - lse_row[i]) + exp(z_ij - lse_col[j])
+ *   - 2*[j == i+offset] ) * b_j   with z_ij = <a_i,b_j>*inv_temp — the gradient of
+ *   (CE_rows + CE_cols) w.r.t. the normalised local rows; coef = inv_temp / (2*Bg).
+ *   (This round the [Bl,Bg] weight tile is staged through `workspace`; see DESIGN.md.)
+ * cosine_loss: loss_sum = sum_b (1 - cos_b), cos[b] kept for the backward, which returns
+ *   ds = -coef * d cos / d s   (training/CLIP_image_distillation.py:564-576).
+ * sub_reduce: out (+)= scale * sum_i (a[i] - b[i])  (b may be NULL) — fixed-order scalar reduction.
+ */
+int dclip_normalize_rows_fwd(const float* x, float* xhat, float* inv_norm, int B, int P, float eps, void* stream);
+int dclip_normalize_rows_bwd(const float* dxhat, const float* xhat, const float* inv_norm, float* dx, int B,
+                             int P, float eps, int accumulate, void* stream);
+size_t dclip_contrastive_workspace(int Bl, int Bg, int P);
+int dclip_contrastive_lse(const float* a_local, const float* b_global, float* lse, float* diag, int Bl, int Bg,
+                          int P, int offset, float inv_temp, void* workspace, size_t workspace_bytes,
+                          void* stream);
+int dclip_contrastive_grad(const float* a_local, const float* b_global, const float* lse_row,
+                           const float* lse_col, float* da_local, int Bl, int Bg, int P, int offset,
+                           float inv_temp, float coef, void* workspace, size_t workspace_bytes, void* stream);
+int dclip_cosine_loss_fwd(const float* s, const float* t, float* loss_sum, float* cos, int B, int P,
+                          void* stream);
+int dclip_cosine_loss_bwd(const float* s, const float* t, const float* cos, float* ds, int B, int P, float coef,
+                          int accumulate, void* stream);
+int dclip_sub_reduce(const float* a, const float* b, float* out, int n, float scale, int accumulate,
+                     void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Small elementwise helpers used between the ops above (all fp32, 16-byte vectorised).
+ */
+int dclip_axpby(const float* x, float* y, float a, float b, size_t n, void* stream); /* y = a*x + b*y */
+int dclip_fill(float* y, float v, size_t n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DCLIP_HIP_H */

@@ -57,8 +57,9 @@ def softmax_lastdim(s: Tensor) -> Tensor:
 
 
 def l2_normalize(x: Tensor, eps: float = 1e-12) -> Tensor:
-    """F.normalize(x, dim=1): x / max(||x||, eps) — CLIP_image_distillation.py:545-546, :569-570."""
-    n = torch.sqrt((x * x).sum(dim=-1, keepdim=True))
+    """F.normalize(x, dim=1): x / max(||x||, eps) — CLIP_image_distillation.py:545-546, :569-570.
+    vector_norm (not sqrt(sum)) so that a zero row back-propagates dy/eps like ATen does, not NaN."""
+    n = torch.linalg.vector_norm(x, dim=-1, keepdim=True)
     return x / torch.clamp(n, min=eps)
 
 
