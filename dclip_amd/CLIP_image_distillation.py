@@ -1,0 +1,181 @@
+"""`CLIPImageDistillation` — the student distillation module, same name and call surface as the reference's
+LightningModule (training/CLIP_image_distillation.py:439-763), with every dense operation on the HIP kernels.
+
+Two batch formats are accepted by `training_step` / `validation_step`:
+  * the reference's tuple `(images[B,3,224,224], captions: list[str], image_paths: list[str], weighted_boxes)`
+    (:594) — needs `clip_preprocess` for tokenisation and real image files for the teacher's crops;
+  * a tensor dict for synthetic / pre-tokenised data (BASELINE.json configs): `pixel_values`, `input_ids`, and
+    either `teacher_image_emb` [B,P] or `regions` [B,R,3,H,W] (+ `region_counts` [B]) for the meta-teacher.
+
+freeze_mode:
+  "north_star"  text tower frozen, vision tower fully trainable (README.md:7; BASELINE.json north_star).
+  "as_written"  what the reference's __init__ actually leaves trainable (:504-506 and nothing else): vision
+                q/k/v/out projections + both projection heads + logit_scale + the whole text tower.
+"""
+from __future__ import annotations
+
+import argparse
+from typing import Dict, Optional
+
+import torch
+
+from . import functional
+from .clip_model import HipCLIPModel, from_hf_state_dict
+from .config import from_hf
+from .lightning_lite import LightningLikeModule
+
+
+def distill_losses(student_image: torch.Tensor, student_text: torch.Tensor, teacher_image: torch.Tensor,
+                   teacher_text: torch.Tensor, temperature: float = 0.05, group=None) -> Dict[str, torch.Tensor]:
+    """loss = L_img + L_txt + 1.0 * L_con  (training/CLIP_image_distillation.py:602, :618, :621-628)."""
+    l_img = functional.cosine_distillation_loss(student_image, teacher_image)
+    l_txt = functional.cosine_distillation_loss(student_text, teacher_text)
+    l_con = functional.contrastive_loss(student_image, student_text, temperature, group)
+    return {"loss": l_img + l_txt + 1.0 * l_con, "loss_image": l_img, "loss_text": l_txt, "loss_contrastive": l_con}
+
+
+def _as_hip_model(clip_model) -> HipCLIPModel:
+    if isinstance(clip_model, HipCLIPModel):
+        return clip_model
+    if hasattr(clip_model, "config") and hasattr(clip_model, "state_dict"):       # an HF CLIPModel
+        dev = next(clip_model.parameters()).device
+        return from_hf_state_dict(from_hf(clip_model.config), clip_model.state_dict(), device=dev)
+    raise TypeError("clip_model must be a dclip_amd HipCLIPModel or a transformers CLIPModel")
+
+
+class CLIPImageDistillation(LightningLikeModule):
+    def __init__(self, hparams, clip_model, clip_preprocess=None, teacher=None, freeze_mode: str = "north_star",
+                 process_group=None, contrastive_teacher_path: Optional[str] = None):
+        super().__init__()
+        self.save_hyperparameters(hparams, ignore="clip_model")
+        self.student = _as_hip_model(clip_model)
+        self.preprocess = clip_preprocess
+        self.process_group = process_group
+        self.temperature = 0.05
+        if teacher is None:
+            from .patch_text_aggregation import PatchTextAggregation
+            teacher = PatchTextAggregation(embed_dim=self.student.config.projection_dim, clip_model=self.student)
+        self.teacher = teacher
+        if contrastive_teacher_path:
+            # weights_only: a checkpoint is data, nothing in it is executed (training/CLIP_image_distillation.py:458-462)
+            sd = torch.load(contrastive_teacher_path, map_location="cpu", weights_only=True)
+            self.teacher.load_state_dict(sd, strict=False)
+        self.teacher.eval()
+        self.set_freeze_mode(freeze_mode)
+
+    # ------------------------------------------------------------------ freeze rules
+    def set_freeze_mode(self, mode: str):
+        if mode not in ("north_star", "as_written"):
+            raise ValueError(f"freeze_mode {mode!r}")
+        self.freeze_mode = mode
+        for p in self.student.parameters():
+            p.requires_grad = True
+        if mode == "as_written":
+            for name, param in self.student.vision_model.named_parameters():      # verbatim rule, :504-506
+                if "proj" not in name:
+                    param.requires_grad = False
+        else:
+            for p in self.student.text_model.parameters():
+                p.requires_grad = False
+            self.student.text_projection.weight.requires_grad = False
+            self.student.logit_scale.requires_grad = False        # unused by the loss (temperature is 0.05)
+        for p in self.teacher.parameters():
+            p.requires_grad = False
+
+    # ------------------------------------------------------------------ reference methods
+    def forward(self, text=None, image=None):
+        """:508-527 — `image` may be PIL (needs clip_preprocess) or a ready [B,3,H,W] tensor; `text` a str /
+        list[str] (needs clip_preprocess) or an int64 id tensor."""
+        if image is not None:
+            if not isinstance(image, torch.Tensor):
+                image = self.preprocess(images=image, return_tensors="pt")["pixel_values"]
+            return self.student.get_image_features(pixel_values=image.to(self.device))
+        if text is not None:
+            if not isinstance(text, torch.Tensor):
+                text = self.preprocess(text=text, return_tensors="pt", padding=True, truncation=True,
+                                       max_length=77)["input_ids"]
+            return self.student.get_text_features(input_ids=text.to(self.device))
+        raise ValueError("Either text or image must be provided.")
+
+    def compute_contrastive_loss(self, image_embeddings, text_embeddings, temperature=0.05):
+        return functional.contrastive_loss(image_embeddings, text_embeddings, temperature, self.process_group)
+
+    def cosine_distillation_loss(self, student_embeddings, teacher_embeddings):
+        return functional.cosine_distillation_loss(student_embeddings, teacher_embeddings)
+
+    def _tokenize(self, captions):
+        if self.preprocess is None:
+            raise RuntimeError("caption strings need clip_preprocess (an HF CLIPProcessor loaded from a local path)")
+        return self.preprocess(text=captions, return_tensors="pt", padding=True, truncation=True)["input_ids"]
+
+    def _step(self, batch, log_name: str, bs_field: str):
+        dev = self.device
+        if isinstance(batch, dict):
+            images = batch["pixel_values"].to(dev)
+            tokens = batch["input_ids"].to(dev)
+            with torch.no_grad():
+                if "teacher_image_emb" in batch:
+                    teacher_image = batch["teacher_image_emb"].to(dev).float()
+                else:
+                    teacher_image = self.teacher.compute_global_embedding_tensors(
+                        batch["regions"].to(dev), tokens, batch.get("region_counts")).float()
+                teacher_text = batch["teacher_text_emb"].to(dev).float() if "teacher_text_emb" in batch else None
+        else:
+            images, captions, image_paths, weighted_boxes_batch = batch
+            images = images.to(dev)
+            tokens = self._tokenize(captions).to(dev)
+            with torch.no_grad():
+                teacher_image = self.teacher.compute_global_embedding_batch(
+                    image_paths, captions, weighted_boxes_batch).to(dev).float()
+            teacher_text = None
+        student_image = self.student.get_image_features(pixel_values=images).float()
+        loss_image = self.cosine_distillation_loss(student_image, teacher_image)
+        student_text = self.student.get_text_features(input_ids=tokens).float()
+        if teacher_text is None:
+            with torch.no_grad():
+                if self.teacher.shares_text_tower_with(self.student):
+                    # frozen student text tower == teacher text tower: one forward serves both
+                    teacher_text = student_text.detach()
+                else:
+                    teacher_text = self.teacher.text_tokenizer.aggregate_text_ids(tokens).float()
+        loss_text = self.cosine_distillation_loss(student_text, teacher_text)
+        contrastive = self.compute_contrastive_loss(student_image, student_text)
+        loss = loss_image + loss_text + 1.0 * contrastive
+        self.last_losses = {"loss_image": loss_image.detach(), "loss_text": loss_text.detach(),
+                            "loss_contrastive": contrastive.detach()}
+        self.log(log_name, loss.detach(), prog_bar=True, batch_size=getattr(self.hparams, bs_field, None))
+        return loss
+
+    def training_step(self, batch, batch_idx: int = 0):
+        return self._step(batch, "train_loss", "train_batch_size")
+
+    def validation_step(self, batch, batch_idx: int = 0):
+        return self._step(batch, "val_loss", "eval_batch_size")
+
+    def configure_optimizers(self):
+        """AdamW over self.parameters() + linear warmup/decay (:679-682; HF get_linear_schedule_with_warmup)."""
+        lr = getattr(self.hparams, "learning_rate", 2e-5)
+        warm = getattr(self.hparams, "warmup_steps", 0)
+        total = getattr(self.hparams, "total_steps", 1000)
+        optimizer = torch.optim.AdamW([p for p in self.parameters() if p.requires_grad], lr=lr)
+
+        def lr_lambda(step: int):
+            if step < warm:
+                return float(step) / float(max(1, warm))
+            return max(0.0, float(total - step) / float(max(1, total - warm)))
+
+        scheduler = torch.optim.lr_scheduler.LambdaLR(optimizer, lr_lambda)
+        return [optimizer], [scheduler]
+
+    @staticmethod
+    def add_model_specific_args(parent_parser: argparse.ArgumentParser) -> argparse.ArgumentParser:
+        """:711-721 — same flags, same defaults, same return value (the parent parser)."""
+        parser = parent_parser.add_argument_group("CLIPImageDistillation")
+        parser.add_argument("--train_file", type=str, required=True, help="Path to the training JSON file.")
+        parser.add_argument("--val_file", type=str, required=False, default=None, help="Path to the validation JSON file.")
+        parser.add_argument("--train_batch_size", type=int, default=32, help="Training batch size.")
+        parser.add_argument("--eval_batch_size", type=int, default=32, help="Evaluation batch size.")
+        parser.add_argument("--learning_rate", type=float, default=2e-5, help="Learning rate.")
+        parser.add_argument("--warmup_steps", type=int, default=0, help="Number of warmup steps.")
+        parser.add_argument("--total_steps", type=int, default=1000, help="Total training steps.")
+        return parent_parser

@@ -46,6 +46,12 @@ SIGNATURES = {
     "dclip_cosine_loss_fwd": (I, [P, P, P, P, I, I, P]),
     "dclip_cosine_loss_bwd": (I, [P, P, P, P, I, I, F, I, P]),
     "dclip_sub_reduce": (I, [P, P, P, I, F, I, P]),
+    "dclip_cross_attention_fwd": (I, [P, P, P, P, I, I, I, I, P]),
+    "dclip_cross_attention_bwd": (I, [P, P, P, P, P, P, P, P, I, I, I, I, P]),
+    "dclip_aggregation_fwd": (I, [P, P, P, I, I, I, F, F, I, P]),
+    "dclip_aggregation_bwd": (I, [P, P, P, P, I, I, I, F, F, P]),
+    "dclip_pack_tokens": (I, [P, P, P, P, I, I, I, I, P]),
+    "dclip_mask_rows": (I, [P, P, I, I, I, P]),
     "dclip_axpby": (I, [P, P, F, F, Z, P]),
     "dclip_fill": (I, [P, F, Z, P]),
 }

@@ -79,9 +79,19 @@ __device__ __forceinline__ void zero4(f32x4 (&a)[4]) {
 }
 
 // ------------------------------------------------------------------------------------------- forward
+// q rows: q + (b*Sq + i)*ldq + h*64;  k/v rows: k + (b*Sk + j)*ldkv + h*64.  Self-attention passes the fused
+// projection (k = q + D, v = q + 2D, ldq = ldkv = 3D, Sq = Sk); cross-attention passes separate buffers.
+struct AttnArgs {
+  const float* q;
+  const float* k;
+  const float* v;
+  int ldq, ldkv;
+  int Sq, Sk, H;
+};
+
 template <bool CAUSAL>
-__global__ void __launch_bounds__(256) attn_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ out,
-                                                       float* __restrict__ lse, int B, int S, int H) {
+__global__ void __launch_bounds__(256) attn_fwd_kernel(AttnArgs a, float* __restrict__ out, float* __restrict__ lse) {
+  const int H = a.H, S = a.Sk, Sq = a.Sq;
   __shared__ __attribute__((aligned(16))) float t0[TS * HD];
   __shared__ __attribute__((aligned(16))) float t1[TS * HD];
   __shared__ __attribute__((aligned(16))) float scratch[4 * 16 * SCR];
@@ -90,11 +100,12 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(const float* __restrict__
   const int bh = blockIdx.x, b = bh / H, h = bh % H;
   const int q0 = blockIdx.y * TS;
   const int D = H * HD;
-  const size_t ld = (size_t)3 * D;
-  const float* base = qkv + (size_t)b * S * ld + h * HD;
+  const float* qbase = a.q + (size_t)b * Sq * a.ldq + h * HD;
+  const float* kbase = a.k + (size_t)b * S * a.ldkv + h * HD;
+  const float* vbase = a.v + (size_t)b * S * a.ldkv + h * HD;
   float* scr = scratch + wave * 16 * SCR;
 
-  stage_tile(t0, base, q0, S, ld);
+  stage_tile(t0, qbase, q0, Sq, (size_t)a.ldq);
   __syncthreads();
   f32x4 qf[4];
 #pragma unroll
@@ -112,8 +123,8 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(const float* __restrict__
   if (CAUSAL) nkt = min(nkt, (int)blockIdx.y + 1);
   for (int kt = 0; kt < nkt; ++kt) {
     __syncthreads();  // everyone is done with t0/t1 of the previous tile (and with the Q fragments load)
-    stage_tile(t0, base + D, kt * TS, S, ld);
-    stage_tile(t1, base + 2 * D, kt * TS, S, ld);
+    stage_tile(t0, kbase, kt * TS, S, (size_t)a.ldkv);
+    stage_tile(t1, vbase, kt * TS, S, (size_t)a.ldkv);
     __syncthreads();
     f32x4 s[4];
     zero4(s);
@@ -161,11 +172,11 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(const float* __restrict__
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int row = q0 + 16 * wave + 4 * qd + r;
-    if (row < S) {
+    if (row < Sq) {
       const float inv = 1.0f / l[r];
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt) out[((size_t)b * S + row) * D + h * HD + nt * 16 + l15] = o[nt][r] * inv;
-      if (l15 == 0) lse[(size_t)bh * S + row] = m[r] + __logf(l[r]);
+      for (int nt = 0; nt < 4; ++nt) out[((size_t)b * Sq + row) * D + h * HD + nt * 16 + l15] = o[nt][r] * inv;
+      if (l15 == 0) lse[(size_t)bh * Sq + row] = m[r] + __logf(l[r]);
     }
   }
 }
@@ -173,10 +184,10 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(const float* __restrict__
 // ------------------------------------------------------------------------------------------- backward: dQ
 // also writes delta[bh, row] = sum_d dO * O for the dK/dV kernel
 template <bool CAUSAL>
-__global__ void __launch_bounds__(256) attn_bwd_dq_kernel(const float* __restrict__ qkv, const float* __restrict__ out,
+__global__ void __launch_bounds__(256) attn_bwd_dq_kernel(AttnArgs a, const float* __restrict__ out,
                                                           const float* __restrict__ dout, const float* __restrict__ lse,
-                                                          float* __restrict__ dqkv, float* __restrict__ delta, int B,
-                                                          int S, int H) {
+                                                          float* __restrict__ dq_out, int lddq, float* __restrict__ delta) {
+  const int H = a.H, S = a.Sk, Sq = a.Sq;
   __shared__ __attribute__((aligned(16))) float t0[TS * HD];
   __shared__ __attribute__((aligned(16))) float t1[TS * HD];
   __shared__ __attribute__((aligned(16))) float scratch[4 * 16 * SCR];
@@ -186,16 +197,17 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(const float* __restric
   const int bh = blockIdx.x, b = bh / H, h = bh % H;
   const int q0 = blockIdx.y * TS;
   const int D = H * HD;
-  const size_t ld = (size_t)3 * D;
-  const float* base = qkv + (size_t)b * S * ld + h * HD;
-  const float* obase = out + (size_t)b * S * D + h * HD;
-  const float* dobase = dout + (size_t)b * S * D + h * HD;
+  const float* qbase = a.q + (size_t)b * Sq * a.ldq + h * HD;
+  const float* kbase = a.k + (size_t)b * S * a.ldkv + h * HD;
+  const float* vbase = a.v + (size_t)b * S * a.ldkv + h * HD;
+  const float* obase = out + (size_t)b * Sq * D + h * HD;
+  const float* dobase = dout + (size_t)b * Sq * D + h * HD;
   float* scr = scratch + wave * 16 * SCR;
 
   {  // delta: 4 threads per row, 16 floats each
     const int row = threadIdx.x >> 2, part = threadIdx.x & 3;
     float s = 0.f;
-    if (q0 + row < S) {
+    if (q0 + row < Sq) {
       const f32x4* po = reinterpret_cast<const f32x4*>(obase + (size_t)(q0 + row) * D + part * 16);
       const f32x4* pd = reinterpret_cast<const f32x4*>(dobase + (size_t)(q0 + row) * D + part * 16);
 #pragma unroll
@@ -208,11 +220,11 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(const float* __restric
     s += __shfl_xor(s, 2, 64);
     if (part == 0) {
       dl_s[row] = s;
-      if (q0 + row < S) delta[(size_t)bh * S + q0 + row] = s;
+      if (q0 + row < Sq) delta[(size_t)bh * Sq + q0 + row] = s;
     }
   }
-  stage_tile(t0, base, q0, S, ld);
-  stage_tile(t1, dobase, q0, S, (size_t)D);
+  stage_tile(t0, qbase, q0, Sq, (size_t)a.ldq);
+  stage_tile(t1, dobase, q0, Sq, (size_t)D);
   __syncthreads();
   f32x4 qf[4], dof[4];
 #pragma unroll
@@ -224,7 +236,7 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(const float* __restric
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int row = q0 + 16 * wave + 4 * qd + r;
-    lse_r[r] = (row < S) ? lse[(size_t)bh * S + row] : 0.f;
+    lse_r[r] = (row < Sq) ? lse[(size_t)bh * Sq + row] : 0.f;
     dl[r] = dl_s[16 * wave + 4 * qd + r];
   }
   f32x4 dq[4];
@@ -233,8 +245,8 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(const float* __restric
   if (CAUSAL) nkt = min(nkt, (int)blockIdx.y + 1);
   for (int kt = 0; kt < nkt; ++kt) {
     __syncthreads();
-    stage_tile(t0, base + D, kt * TS, S, ld);
-    stage_tile(t1, base + 2 * D, kt * TS, S, ld);
+    stage_tile(t0, kbase, kt * TS, S, (size_t)a.ldkv);
+    stage_tile(t1, vbase, kt * TS, S, (size_t)a.ldkv);
     __syncthreads();
     f32x4 s[4], dp[4];
     zero4(s);
@@ -258,17 +270,19 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(const float* __restric
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int row = q0 + 16 * wave + 4 * qd + r;
-    if (row < S)
+    if (row < Sq)
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt) dqkv[((size_t)b * S + row) * ld + h * HD + nt * 16 + l15] = dq[nt][r];
+      for (int nt = 0; nt < 4; ++nt) dq_out[((size_t)b * Sq + row) * lddq + h * HD + nt * 16 + l15] = dq[nt][r];
   }
 }
 
 // ------------------------------------------------------------------------------------------- backward: dK, dV
 template <bool CAUSAL>
-__global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
+__global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(AttnArgs a, const float* __restrict__ dout,
                                                            const float* __restrict__ lse, const float* __restrict__ delta,
-                                                           float* __restrict__ dqkv, int B, int S, int H) {
+                                                           float* __restrict__ dk_out, float* __restrict__ dv_out,
+                                                           int lddkv) {
+  const int H = a.H, S = a.Sk, Sq = a.Sq;
   __shared__ __attribute__((aligned(16))) float t0[TS * HD];
   __shared__ __attribute__((aligned(16))) float t1[TS * HD];
   __shared__ __attribute__((aligned(16))) float scratch_p[4 * 16 * SCR];
@@ -279,14 +293,15 @@ __global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(const float* __restri
   const int bh = blockIdx.x, b = bh / H, h = bh % H;
   const int k0 = blockIdx.y * TS;
   const int D = H * HD;
-  const size_t ld = (size_t)3 * D;
-  const float* base = qkv + (size_t)b * S * ld + h * HD;
-  const float* dobase = dout + (size_t)b * S * D + h * HD;
+  const float* qbase = a.q + (size_t)b * Sq * a.ldq + h * HD;
+  const float* kbase = a.k + (size_t)b * S * a.ldkv + h * HD;
+  const float* vbase = a.v + (size_t)b * S * a.ldkv + h * HD;
+  const float* dobase = dout + (size_t)b * Sq * D + h * HD;
   float* scp = scratch_p + wave * 16 * SCR;
   float* scs = scratch_s + wave * 16 * SCR;
 
-  stage_tile(t0, base + D, k0, S, ld);
-  stage_tile(t1, base + 2 * D, k0, S, ld);
+  stage_tile(t0, kbase, k0, S, (size_t)a.ldkv);
+  stage_tile(t1, vbase, k0, S, (size_t)a.ldkv);
   __syncthreads();
   f32x4 kf[4], vf[4];
 #pragma unroll
@@ -297,16 +312,16 @@ __global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(const float* __restri
   f32x4 dk[4], dv[4];
   zero4(dk);
   zero4(dv);
-  const int nqt = (S + TS - 1) / TS;
+  const int nqt = (Sq + TS - 1) / TS;
   for (int qt = CAUSAL ? (int)blockIdx.y : 0; qt < nqt; ++qt) {
     const int q0 = qt * TS;
     __syncthreads();
-    stage_tile(t0, base, q0, S, ld);
-    stage_tile(t1, dobase, q0, S, (size_t)D);
+    stage_tile(t0, qbase, q0, Sq, (size_t)a.ldq);
+    stage_tile(t1, dobase, q0, Sq, (size_t)D);
     if (threadIdx.x < TS) {
       const int q = q0 + threadIdx.x;
-      lse_s[threadIdx.x] = (q < S) ? lse[(size_t)bh * S + q] : 0.f;
-      dl_s[threadIdx.x] = (q < S) ? delta[(size_t)bh * S + q] : 0.f;
+      lse_s[threadIdx.x] = (q < Sq) ? lse[(size_t)bh * Sq + q] : 0.f;
+      dl_s[threadIdx.x] = (q < Sq) ? delta[(size_t)bh * Sq + q] : 0.f;
     }
     __syncthreads();
     f32x4 st[4], dpt[4];
@@ -321,7 +336,7 @@ __global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(const float* __restri
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int key = k0 + 16 * wave + 4 * qd + r;
-        const bool masked = key >= S || q >= S || (CAUSAL && key > q);
+        const bool masked = key >= S || q >= Sq || (CAUSAL && key > q);
         const float p = masked ? 0.f : __expf(st[nt][r] * kScale - lq);
         scp[(4 * qd + r) * SCR + ql] = p;
         scs[(4 * qd + r) * SCR + ql] = p * (dpt[nt][r] - dq_) * kScale;
@@ -337,11 +352,37 @@ __global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(const float* __restri
     if (key < S)
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) {
-        const size_t o = ((size_t)b * S + key) * ld + h * HD + nt * 16 + l15;
-        dqkv[o + D] = dk[nt][r];
-        dqkv[o + 2 * D] = dv[nt][r];
+        const size_t o = ((size_t)b * S + key) * lddkv + h * HD + nt * 16 + l15;
+        dk_out[o] = dk[nt][r];
+        dv_out[o] = dv[nt][r];
       }
   }
+}
+
+}  // namespace
+
+namespace {
+
+int launch_fwd(const AttnArgs& a, float* out, float* lse, int B, int causal, hipStream_t st) {
+  dim3 grid(B * a.H, cdiv(a.Sq, TS)), block(256);
+  if (causal) hipLaunchKernelGGL((attn_fwd_kernel<true>), grid, block, 0, st, a, out, lse);
+  else hipLaunchKernelGGL((attn_fwd_kernel<false>), grid, block, 0, st, a, out, lse);
+  DCLIP_CHECK_LAUNCH("attention_fwd");
+  return DCLIP_OK;
+}
+
+int launch_bwd(const AttnArgs& a, const float* out, const float* dout, const float* lse, float* dq, int lddq, float* dk,
+               float* dv, int lddkv, float* delta, int B, int causal, hipStream_t st) {
+  dim3 gq(B * a.H, cdiv(a.Sq, TS)), gk(B * a.H, cdiv(a.Sk, TS)), block(256);
+  if (causal) {
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<true>), gq, block, 0, st, a, out, dout, lse, dq, lddq, delta);
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<true>), gk, block, 0, st, a, dout, lse, delta, dk, dv, lddkv);
+  } else {
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<false>), gq, block, 0, st, a, out, dout, lse, dq, lddq, delta);
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<false>), gk, block, 0, st, a, dout, lse, delta, dk, dv, lddkv);
+  }
+  DCLIP_CHECK_LAUNCH("attention_bwd");
+  return DCLIP_OK;
 }
 
 }  // namespace
@@ -350,27 +391,35 @@ DCLIP_API int dclip_attention_fwd(const float* qkv, float* out, float* lse, int 
                                   void* stream) {
   DCLIP_REQUIRE(qkv && out && lse, "attention_fwd: null pointer");
   DCLIP_REQUIRE(B > 0 && S > 0 && H > 0, "attention_fwd: bad shape B=%d S=%d H=%d", B, S, H);
-  dim3 grid(B * H, cdiv(S, TS)), block(256);
-  hipStream_t st = (hipStream_t)stream;
-  if (causal) hipLaunchKernelGGL((attn_fwd_kernel<true>), grid, block, 0, st, qkv, out, lse, B, S, H);
-  else hipLaunchKernelGGL((attn_fwd_kernel<false>), grid, block, 0, st, qkv, out, lse, B, S, H);
-  DCLIP_CHECK_LAUNCH("attention_fwd");
-  return DCLIP_OK;
+  const int D = H * HD;
+  AttnArgs a{qkv, qkv + D, qkv + 2 * D, 3 * D, 3 * D, S, S, H};
+  return launch_fwd(a, out, lse, B, causal, (hipStream_t)stream);
 }
 
 DCLIP_API int dclip_attention_bwd(const float* qkv, const float* out, const float* dout, const float* lse,
                                   float* dqkv, float* delta, int B, int S, int H, int causal, void* stream) {
   DCLIP_REQUIRE(qkv && out && dout && lse && dqkv && delta, "attention_bwd: null pointer");
   DCLIP_REQUIRE(B > 0 && S > 0 && H > 0, "attention_bwd: bad shape B=%d S=%d H=%d", B, S, H);
-  dim3 grid(B * H, cdiv(S, TS)), block(256);
-  hipStream_t st = (hipStream_t)stream;
-  if (causal) {
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<true>), grid, block, 0, st, qkv, out, dout, lse, dqkv, delta, B, S, H);
-    hipLaunchKernelGGL((attn_bwd_dkv_kernel<true>), grid, block, 0, st, qkv, dout, lse, delta, dqkv, B, S, H);
-  } else {
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<false>), grid, block, 0, st, qkv, out, dout, lse, dqkv, delta, B, S, H);
-    hipLaunchKernelGGL((attn_bwd_dkv_kernel<false>), grid, block, 0, st, qkv, dout, lse, delta, dqkv, B, S, H);
-  }
-  DCLIP_CHECK_LAUNCH("attention_bwd");
-  return DCLIP_OK;
+  const int D = H * HD;
+  AttnArgs a{qkv, qkv + D, qkv + 2 * D, 3 * D, 3 * D, S, S, H};
+  return launch_bwd(a, out, dout, lse, dqkv, 3 * D, dqkv + D, dqkv + 2 * D, 3 * D, delta, B, causal, (hipStream_t)stream);
+}
+
+DCLIP_API int dclip_cross_attention_fwd(const float* q, const float* kv, float* out, float* lse, int B, int Lq, int Lk,
+                                        int H, void* stream) {
+  DCLIP_REQUIRE(q && kv && out && lse, "cross_attention_fwd: null pointer");
+  DCLIP_REQUIRE(B > 0 && Lq > 0 && Lk > 0 && H > 0, "cross_attention_fwd: bad shape B=%d Lq=%d Lk=%d H=%d", B, Lq, Lk, H);
+  const int E = H * HD;
+  AttnArgs a{q, kv, kv + E, E, 2 * E, Lq, Lk, H};
+  return launch_fwd(a, out, lse, B, 0, (hipStream_t)stream);
+}
+
+DCLIP_API int dclip_cross_attention_bwd(const float* q, const float* kv, const float* out, const float* dout,
+                                        const float* lse, float* dq, float* dkv, float* delta, int B, int Lq, int Lk,
+                                        int H, void* stream) {
+  DCLIP_REQUIRE(q && kv && out && dout && lse && dq && dkv && delta, "cross_attention_bwd: null pointer");
+  DCLIP_REQUIRE(B > 0 && Lq > 0 && Lk > 0 && H > 0, "cross_attention_bwd: bad shape");
+  const int E = H * HD;
+  AttnArgs a{q, kv, kv + E, E, 2 * E, Lq, Lk, H};
+  return launch_bwd(a, out, dout, lse, dq, E, dkv, dkv + E, 2 * E, delta, B, 0, (hipStream_t)stream);
 }

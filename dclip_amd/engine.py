@@ -1,0 +1,327 @@
+"""Explicit forward / backward schedules of the CLIP towers over the C-ABI kernels.
+
+No tracing compiler and no autograd inside a tower: each function below is the fixed launch
+sequence for one pre-LN transformer stack (hf:modeling_clip.py:362-383) and its hand-derived
+backward.  `functional.py` wraps a whole tower as ONE torch.autograd.Function so that the
+reference's training scripts (`loss.backward()`, torch optimizers) keep working unchanged.
+
+Shapes: activations are [M = B*S, D] row-major.  Per layer the forward keeps
+(x, ln1, qkv, attn, lse, x1, ln2, h, g + LN statistics) for the backward; with 288 GB of HBM per
+MI355X nothing is recomputed (12 layers x ~630 MB at B=256, S=50, D=768).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Dict, List, Optional
+
+import torch
+
+from . import ops
+
+
+@dataclass
+class LayerParams:
+    ln1_w: torch.Tensor
+    ln1_b: torch.Tensor
+    qkv_w: torch.Tensor      # [3D, D] = rows [q | k | v], the in-memory fusion of q_proj/k_proj/v_proj
+    qkv_b: torch.Tensor
+    out_w: torch.Tensor
+    out_b: torch.Tensor
+    ln2_w: torch.Tensor
+    ln2_b: torch.Tensor
+    fc1_w: torch.Tensor
+    fc1_b: torch.Tensor
+    fc2_w: torch.Tensor
+    fc2_b: torch.Tensor
+
+    FIELDS = ("ln1_w", "ln1_b", "qkv_w", "qkv_b", "out_w", "out_b", "ln2_w", "ln2_b", "fc1_w", "fc1_b", "fc2_w",
+              "fc2_b")
+
+    def tensors(self):
+        return [getattr(self, f) for f in self.FIELDS]
+
+
+def layer_fwd(x, p: LayerParams, B: int, S: int, H: int, causal: bool, eps: float, save: bool):
+    ln1, m1, r1 = ops.layernorm_fwd(x, p.ln1_w, p.ln1_b, eps, save_stats=save)
+    qkv = ops.gemm(ln1, p.qkv_w, ops.LAYOUT_NT, bias=p.qkv_b)
+    attn, lse = ops.attention_fwd(qkv, B, S, H, causal)
+    x1 = ops.gemm(attn, p.out_w, ops.LAYOUT_NT, bias=p.out_b, residual=x)
+    ln2, m2, r2 = ops.layernorm_fwd(x1, p.ln2_w, p.ln2_b, eps, save_stats=save)
+    h = torch.empty((x.shape[0], p.fc1_w.shape[0]), dtype=torch.float32, device=x.device) if save else None
+    g = ops.gemm(ln2, p.fc1_w, ops.LAYOUT_NT, bias=p.fc1_b, aux=h, epilogue=ops.EPI_GELU)
+    x2 = ops.gemm(g, p.fc2_w, ops.LAYOUT_NT, bias=p.fc2_b, residual=x1)
+    saved = (x, m1, r1, ln1, qkv, attn, lse, x1, m2, r2, ln2, h, g) if save else None
+    return x2, saved
+
+
+def layer_bwd(dx2, p: LayerParams, saved, B: int, S: int, H: int, causal: bool, need: Dict[str, bool]):
+    """Returns (dx, grads) with grads keyed like LayerParams.FIELDS (missing = not needed)."""
+    x, m1, r1, ln1, qkv, attn, lse, x1, m2, r2, ln2, h, g = saved
+    gr: Dict[str, torch.Tensor] = {}
+    if need.get("fc2_w"):
+        gr["fc2_w"] = ops.gemm(dx2, g, ops.LAYOUT_TN)
+    if need.get("fc2_b"):
+        gr["fc2_b"] = ops.colsum(dx2)
+    dh = ops.gemm(dx2, p.fc2_w, ops.LAYOUT_NN, aux=h, epilogue=ops.EPI_DGELU)
+    if need.get("fc1_w"):
+        gr["fc1_w"] = ops.gemm(dh, ln2, ops.LAYOUT_TN)
+    if need.get("fc1_b"):
+        gr["fc1_b"] = ops.colsum(dh)
+    dln2 = ops.gemm(dh, p.fc1_w, ops.LAYOUT_NN)
+    del dh
+    want_ln2 = bool(need.get("ln2_w") or need.get("ln2_b"))
+    dx1, dg, db = ops.layernorm_bwd(dln2, x1, p.ln2_w, m2, r2, dresidual=dx2, need_param_grads=want_ln2)
+    if want_ln2:
+        gr["ln2_w"], gr["ln2_b"] = dg, db
+    if need.get("out_w"):
+        gr["out_w"] = ops.gemm(dx1, attn, ops.LAYOUT_TN)
+    if need.get("out_b"):
+        gr["out_b"] = ops.colsum(dx1)
+    dattn = ops.gemm(dx1, p.out_w, ops.LAYOUT_NN)
+    dqkv = ops.attention_bwd(qkv, attn, dattn, lse, B, S, H, causal)
+    if need.get("qkv_w"):
+        gr["qkv_w"] = ops.gemm(dqkv, ln1, ops.LAYOUT_TN)
+    if need.get("qkv_b"):
+        gr["qkv_b"] = ops.colsum(dqkv)
+    dln1 = ops.gemm(dqkv, p.qkv_w, ops.LAYOUT_NN)
+    del dqkv
+    want_ln1 = bool(need.get("ln1_w") or need.get("ln1_b"))
+    dx, dg, db = ops.layernorm_bwd(dln1, x, p.ln1_w, m1, r1, dresidual=dx1, need_param_grads=want_ln1)
+    if want_ln1:
+        gr["ln1_w"], gr["ln1_b"] = dg, db
+    return dx, gr
+
+
+# --------------------------------------------------------------------------------------------- vision tower
+
+@dataclass
+class VisionParams:
+    class_embedding: torch.Tensor
+    patch_w: torch.Tensor        # [D, C, p, p]
+    pos: torch.Tensor            # [S, D]
+    pre_w: torch.Tensor
+    pre_b: torch.Tensor
+    layers: List[LayerParams]
+    post_w: torch.Tensor
+    post_b: torch.Tensor
+    proj_w: torch.Tensor         # visual_projection [P, D]
+
+    HEAD = ("class_embedding", "patch_w", "pos", "pre_w", "pre_b")
+    TAIL = ("post_w", "post_b", "proj_w")
+
+    def tensors(self):
+        out = [getattr(self, f) for f in self.HEAD]
+        for l in self.layers:
+            out += l.tensors()
+        out += [getattr(self, f) for f in self.TAIL]
+        return out
+
+    @classmethod
+    def from_tensors(cls, ts, n_layers):
+        ts = list(ts)
+        head = ts[:5]
+        layers = [LayerParams(*ts[5 + 12 * i: 5 + 12 * (i + 1)]) for i in range(n_layers)]
+        tail = ts[5 + 12 * n_layers:]
+        return cls(*head, layers, *tail)
+
+    def names(self):
+        out = list(self.HEAD)
+        for i in range(len(self.layers)):
+            out += [f"layers.{i}.{f}" for f in LayerParams.FIELDS]
+        return out + list(self.TAIL)
+
+
+def vision_fwd(p: VisionParams, pixel_values: torch.Tensor, cfg, save: bool, hidden_out: Optional[list] = None):
+    """get_image_features: [B,3,H,W] -> [B,P]  (hf:modeling_clip.py:202-218, :641-651, :744-751)."""
+    v = cfg
+    B = pixel_values.shape[0]
+    S, D, H = v.seq_len, v.hidden_size, v.num_attention_heads
+    cols = ops.im2col(pixel_values, v.patch_size)
+    patch = ops.gemm(cols, p.patch_w.view(D, -1), ops.LAYOUT_NT)
+    emb = ops.vision_assemble_fwd(patch, p.class_embedding, p.pos, B, S, D)
+    del patch
+    x, m0, r0 = ops.layernorm_fwd(emb, p.pre_w, p.pre_b, v.layer_norm_eps, save_stats=save)
+    if hidden_out is not None:
+        hidden_out.append(x)
+    saved_layers = []
+    for lp in p.layers:
+        x, sv = layer_fwd(x, lp, B, S, H, False, v.layer_norm_eps, save)
+        saved_layers.append(sv)
+        if hidden_out is not None:
+            hidden_out.append(x)
+    cls_tok = ops.gather_rows(x, None, B, S, D)
+    pooled, mp, rp = ops.layernorm_fwd(cls_tok, p.post_w, p.post_b, v.layer_norm_eps, save_stats=save)
+    out = ops.gemm(pooled, p.proj_w, ops.LAYOUT_NT)
+    saved = (cols, emb, m0, r0, saved_layers, cls_tok, mp, rp, pooled) if save else None
+    return out, saved
+
+
+def vision_bwd(p: VisionParams, saved, d_out: torch.Tensor, cfg, need: List[bool]):
+    """Gradients for VisionParams.tensors() order (None where not needed)."""
+    v = cfg
+    cols, emb, m0, r0, saved_layers, cls_tok, mp, rp, pooled = saved
+    B = cls_tok.shape[0]
+    S, D, H = v.seq_len, v.hidden_size, v.num_attention_heads
+    names = p.names()
+    needd = dict(zip(names, need))
+    grads: Dict[str, Optional[torch.Tensor]] = {n: None for n in names}
+    if needd["proj_w"]:
+        grads["proj_w"] = ops.gemm(d_out, pooled, ops.LAYOUT_TN)
+    dpooled = ops.gemm(d_out, p.proj_w, ops.LAYOUT_NN)
+    want = needd["post_w"] or needd["post_b"]
+    dcls, dg, db = ops.layernorm_bwd(dpooled, cls_tok, p.post_w, mp, rp, need_param_grads=want)
+    if want:
+        grads["post_w"], grads["post_b"] = dg, db
+    dx = ops.scatter_rows(dcls, None, B, S, D)
+    n_layers = len(p.layers)
+    # stop as soon as nothing below still needs a gradient (e.g. only visual_projection trainable)
+    lowest = None
+    for i, n in enumerate(names):
+        if needd[n] and n not in VisionParams.TAIL:
+            li = -1 if n in VisionParams.HEAD else int(n.split(".")[1])
+            lowest = li if lowest is None else min(lowest, li)
+    if lowest is None:
+        return [grads[n] for n in names]
+    for i in range(n_layers - 1, max(lowest, 0) - 1, -1):
+        lneed = {f: needd[f"layers.{i}.{f}"] for f in LayerParams.FIELDS}
+        dx, gr = layer_bwd(dx, p.layers[i], saved_layers[i], B, S, H, False, lneed)
+        saved_layers[i] = None
+        for f, t in gr.items():
+            grads[f"layers.{i}.{f}"] = t
+    if lowest < 0:
+        want = needd["pre_w"] or needd["pre_b"]
+        demb, dg, db = ops.layernorm_bwd(dx, emb, p.pre_w, m0, r0, need_param_grads=want)
+        if want:
+            grads["pre_w"], grads["pre_b"] = dg, db
+        if needd["pos"] or needd["class_embedding"]:
+            dpos = ops.colsum(demb.view(B, S * D))
+            if needd["pos"]:
+                grads["pos"] = dpos.view(S, D)
+            if needd["class_embedding"]:
+                grads["class_embedding"] = dpos[:D].clone()
+        if needd["patch_w"]:
+            dpatch = ops.vision_assemble_bwd(demb, B, S, D)
+            grads["patch_w"] = ops.gemm(dpatch, cols, ops.LAYOUT_TN).view_as(p.patch_w)
+    return [grads[n] for n in names]
+
+
+# --------------------------------------------------------------------------------------------- text tower
+
+@dataclass
+class TextParams:
+    tok: torch.Tensor            # [vocab, D]
+    pos: torch.Tensor            # [Tmax, D]
+    layers: List[LayerParams]
+    final_w: torch.Tensor
+    final_b: torch.Tensor
+    proj_w: torch.Tensor         # text_projection [P, D]
+
+    HEAD = ("tok", "pos")
+    TAIL = ("final_w", "final_b", "proj_w")
+
+    def tensors(self):
+        out = [self.tok, self.pos]
+        for l in self.layers:
+            out += l.tensors()
+        return out + [self.final_w, self.final_b, self.proj_w]
+
+    @classmethod
+    def from_tensors(cls, ts, n_layers):
+        ts = list(ts)
+        layers = [LayerParams(*ts[2 + 12 * i: 2 + 12 * (i + 1)]) for i in range(n_layers)]
+        return cls(ts[0], ts[1], layers, *ts[2 + 12 * n_layers:])
+
+    def names(self):
+        out = list(self.HEAD)
+        for i in range(len(self.layers)):
+            out += [f"layers.{i}.{f}" for f in LayerParams.FIELDS]
+        return out + list(self.TAIL)
+
+
+def text_encoder_fwd(p: TextParams, input_ids: torch.Tensor, cfg, save: bool, hidden_out: Optional[list] = None):
+    """Embeddings + causal stack; returns the PRE-final-LN hidden states [B*T, D]."""
+    t = cfg
+    B, T = input_ids.shape
+    D, H = t.hidden_size, t.num_attention_heads
+    x = ops.text_embed_fwd(input_ids, p.tok, p.pos)
+    if hidden_out is not None:
+        hidden_out.append(x)
+    saved_layers = []
+    for lp in p.layers:
+        x, sv = layer_fwd(x, lp, B, T, H, True, t.layer_norm_eps, save)
+        saved_layers.append(sv)
+        if hidden_out is not None:
+            hidden_out.append(x)
+    return x, saved_layers
+
+
+def text_fwd(p: TextParams, input_ids: torch.Tensor, cfg, save: bool, hidden_out: Optional[list] = None):
+    """get_text_features: ids [B,T] -> [B,P]  (hf:modeling_clip.py:541-586, :705-713).  LayerNorm is row-wise, so
+    the first-EOS rows are gathered BEFORE final_layer_norm: only B rows are normalised and projected."""
+    t = cfg
+    B, T = input_ids.shape
+    D = t.hidden_size
+    x, saved_layers = text_encoder_fwd(p, input_ids, cfg, save, hidden_out)
+    eos = ops.first_eos(input_ids, t.eos_token_id)
+    rows = ops.gather_rows(x, eos, B, T, D)
+    pooled, mp, rp = ops.layernorm_fwd(rows, p.final_w, p.final_b, t.layer_norm_eps, save_stats=save)
+    out = ops.gemm(pooled, p.proj_w, ops.LAYOUT_NT)
+    saved = (input_ids, saved_layers, eos, rows, mp, rp, pooled) if save else None
+    return out, saved
+
+
+def text_bwd(p: TextParams, saved, d_out: torch.Tensor, cfg, need: List[bool]):
+    t = cfg
+    input_ids, saved_layers, eos, rows, mp, rp, pooled = saved
+    B, T = input_ids.shape
+    D, H = t.hidden_size, t.num_attention_heads
+    names = p.names()
+    needd = dict(zip(names, need))
+    grads: Dict[str, Optional[torch.Tensor]] = {n: None for n in names}
+    if needd["proj_w"]:
+        grads["proj_w"] = ops.gemm(d_out, pooled, ops.LAYOUT_TN)
+    dpooled = ops.gemm(d_out, p.proj_w, ops.LAYOUT_NN)
+    want = needd["final_w"] or needd["final_b"]
+    drows, dg, db = ops.layernorm_bwd(dpooled, rows, p.final_w, mp, rp, need_param_grads=want)
+    if want:
+        grads["final_w"], grads["final_b"] = dg, db
+    lowest = None
+    for n in names:
+        if needd[n] and n not in TextParams.TAIL:
+            li = -1 if n in TextParams.HEAD else int(n.split(".")[1])
+            lowest = li if lowest is None else min(lowest, li)
+    if lowest is None:
+        return [grads[n] for n in names]
+    dx = ops.scatter_rows(drows, eos, B, T, D)
+    for i in range(len(p.layers) - 1, max(lowest, 0) - 1, -1):
+        lneed = {f: needd[f"layers.{i}.{f}"] for f in LayerParams.FIELDS}
+        dx, gr = layer_bwd(dx, p.layers[i], saved_layers[i], B, T, H, True, lneed)
+        saved_layers[i] = None
+        for f, tn in gr.items():
+            grads[f"layers.{i}.{f}"] = tn
+    if lowest < 0:
+        if needd["pos"]:
+            dpos = torch.zeros_like(p.pos)
+            dpos[:T] = ops.colsum(dx.view(B, T * D)).view(T, D)
+            grads["pos"] = dpos
+        if needd["tok"]:
+            dtok = torch.zeros_like(p.tok)
+            grads["tok"] = ops.text_embed_bwd(input_ids, dx, dtok)
+    return [grads[n] for n in names]
+
+
+def text_token_level(p: TextParams, input_ids: torch.Tensor, cfg):
+    """Frozen teacher text pass giving BOTH outputs of one forward (the reference runs the tower twice per caption,
+    training/patch_text_aggregation.py:534 and training/CLIP_image_distillation.py:607):
+      sentence [B,P]   = text_projection(final_LN(h)[first EOS])                 (text_tokenizer.py:193,:216)
+      tokens   [B*T,P] = text_projection(final_LN(h)) for every position          (text_tokenizer.py:202-207)
+      eos [B] int32    = first-EOS index; word tokens of caption b are rows 1 .. eos[b]-1."""
+    t = cfg
+    B, T = input_ids.shape
+    D = t.hidden_size
+    x, _ = text_encoder_fwd(p, input_ids, cfg, save=False)
+    ln, _, _ = ops.layernorm_fwd(x, p.final_w, p.final_b, t.layer_norm_eps, save_stats=False)
+    tokens = ops.gemm(ln, p.proj_w, ops.LAYOUT_NT)
+    eos = ops.first_eos(input_ids, t.eos_token_id)
+    sentence = ops.gather_rows(tokens, eos, B, T, tokens.shape[1])
+    return sentence, tokens, eos

@@ -1,0 +1,151 @@
+"""The few pieces of pytorch_lightning the reference leans on, restated (Lightning is not installed here and is
+not on the hot path): a LightningModule-shaped base class, a `fit` loop with the same hook names, gradient
+clipping / accumulation as configured in training/CLIP_image_distill_training.py:36-44, and a `.ckpt` writer /
+reader with Lightning's dictionary layout (SURVEY.md §8b "Student checkpoint").
+
+Host-side plumbing only — no arithmetic of the step lives here.
+"""
+from __future__ import annotations
+
+import argparse
+import os
+from typing import Any, Dict, Iterable, Optional
+
+import torch
+import torch.nn as nn
+
+LIGHTNING_VERSION_TAG = "2.0.0-dclip_amd"
+
+
+class LightningLikeModule(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.hparams = argparse.Namespace()
+        self._logged: Dict[str, float] = {}
+        self.current_epoch = 0
+        self.global_step = 0
+
+    # -- LightningModule surface the reference uses
+    def save_hyperparameters(self, hparams=None, ignore=None):
+        if isinstance(hparams, argparse.Namespace):
+            self.hparams = argparse.Namespace(**vars(hparams))
+        elif isinstance(hparams, dict):
+            self.hparams = argparse.Namespace(**hparams)
+
+    @property
+    def device(self) -> torch.device:
+        for p in self.parameters():
+            return p.device
+        return torch.device("cpu")
+
+    def log(self, name: str, value, prog_bar: bool = False, batch_size: Optional[int] = None, **kw):
+        # keep the device tensor: reading it (.item()) would synchronise the stream every step
+        self._logged[name] = value
+
+    def logged(self, name: str) -> float:
+        v = self._logged[name]
+        return float(v.detach()) if isinstance(v, torch.Tensor) else float(v)
+
+    @classmethod
+    def load_from_checkpoint(cls, checkpoint_path, map_location=None, strict=True, **init_kwargs):
+        """`CLIPImageDistillation.load_from_checkpoint(path, map_location=, clip_model=, clip_preprocess=, strict=False)`
+        as called by eval_scripts/flickr30k_eval.py:126-132."""
+        # weights_only=True: nothing in the file is executed; argparse.Namespace (Lightning stores hparams as one)
+        # is allow-listed explicitly.
+        with torch.serialization.safe_globals([argparse.Namespace]):
+            ckpt = torch.load(checkpoint_path, map_location=map_location or "cpu", weights_only=True)
+        hp = ckpt.get("hyper_parameters", {})
+        hp = hp if isinstance(hp, argparse.Namespace) else argparse.Namespace(**dict(hp))
+        model = cls(hp, **init_kwargs)
+        model.load_state_dict(ckpt["state_dict"], strict=strict)
+        return model
+
+
+def save_checkpoint(path: str, module: LightningLikeModule, optimizer=None, scheduler=None, epoch: int = 0,
+                    global_step: int = 0):
+    """Lightning-layout dictionary: state_dict (prefixes `student.` / `teacher.cross_modal_attention.`),
+    epoch, global_step, hyper_parameters, optimizer_states, lr_schedulers, callbacks, pytorch-lightning_version."""
+    os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+    ckpt = {
+        "epoch": epoch,
+        "global_step": global_step,
+        "pytorch-lightning_version": LIGHTNING_VERSION_TAG,
+        "state_dict": {k: v.detach().cpu() for k, v in module.state_dict().items()},
+        "hyper_parameters": dict(vars(module.hparams)),
+        "optimizer_states": [optimizer.state_dict()] if optimizer is not None else [],
+        "lr_schedulers": [scheduler.state_dict()] if scheduler is not None else [],
+        "callbacks": {},
+    }
+    tmp = path + ".tmp"
+    torch.save(ckpt, tmp)
+    os.replace(tmp, path)
+    return path
+
+
+def checkpoint_filename(epoch: int, train_loss: float) -> str:
+    """ModelCheckpoint(filename="epoch-{epoch:02d}-{train_loss:.2f}") expands to e.g.
+    `epoch-epoch=01-train_loss=3.01.ckpt` (training/CLIP_image_distill_training.py:27-34; the name
+    eval_scripts/flickr30k_eval.py:113 expects)."""
+    return f"epoch-epoch={epoch:02d}-train_loss={train_loss:.2f}.ckpt"
+
+
+class Trainer:
+    """`Trainer(max_epochs, accelerator="gpu", devices=1, precision=32, gradient_clip_val=0.5,
+    accumulate_grad_batches=4, callbacks=[ModelCheckpoint(...)]).fit(model)` — the subset the launcher uses."""
+
+    def __init__(self, max_epochs: int = 1, gradient_clip_val: Optional[float] = 0.5, accumulate_grad_batches: int = 4,
+                 checkpoint_dir: Optional[str] = None, save_top_k: int = 10, max_steps: Optional[int] = None, **_ignored):
+        self.max_epochs = max_epochs
+        self.clip = gradient_clip_val
+        self.accum = max(1, accumulate_grad_batches)
+        self.checkpoint_dir = checkpoint_dir
+        self.save_top_k = save_top_k
+        self.max_steps = max_steps
+        self.saved = []          # (train_loss, path)
+
+    def fit(self, model: LightningLikeModule, train_dataloaders: Optional[Iterable] = None,
+            val_dataloaders: Optional[Iterable] = None):
+        opts, scheds = model.configure_optimizers()
+        opt, sched = opts[0], (scheds[0] if scheds else None)
+        train = train_dataloaders if train_dataloaders is not None else model.train_dataloader()
+        val = val_dataloaders if val_dataloaders is not None else (
+            model.val_dataloader() if hasattr(model, "val_dataloader") else None)
+        step = 0
+        for epoch in range(self.max_epochs):
+            model.current_epoch = epoch
+            model.train()
+            opt.zero_grad(set_to_none=True)
+            last = None
+            for i, batch in enumerate(train):
+                loss = model.training_step(batch)
+                (loss / self.accum).backward()
+                last = loss.detach()
+                if (i + 1) % self.accum == 0:
+                    if self.clip:
+                        torch.nn.utils.clip_grad_norm_([p for p in model.parameters() if p.grad is not None], self.clip)
+                    opt.step()
+                    if sched is not None:
+                        sched.step()
+                    opt.zero_grad(set_to_none=True)
+                    step += 1
+                    model.global_step = step
+                if self.max_steps is not None and step >= self.max_steps:
+                    break
+            if val is not None:
+                model.eval()
+                with torch.no_grad():
+                    for batch in val:
+                        model.validation_step(batch)
+            if self.checkpoint_dir and last is not None:
+                tl = float(last)
+                path = os.path.join(self.checkpoint_dir, checkpoint_filename(epoch, tl))
+                save_checkpoint(path, model, opt, sched, epoch, step)
+                self.saved.append((tl, path))
+                self.saved.sort()
+                for _, stale in self.saved[self.save_top_k:]:
+                    if os.path.exists(stale):
+                        os.remove(stale)
+                self.saved = self.saved[:self.save_top_k]
+            if self.max_steps is not None and step >= self.max_steps:
+                break
+        return model

@@ -397,6 +397,86 @@ def sub_reduce(a, b, scale: float, out=None, accumulate=False):
     return out
 
 
+# ------------------------------------------------------------------------------------------- meta-teacher tail
+
+def cross_attention_fwd(q, kv, B: int, Lq: int, Lk: int, H: int):
+    lib = _lib.load()
+    _f32(q, "q"), _f32(kv, "kv")
+    E = H * 64
+    if q.numel() != B * Lq * E or kv.numel() != B * Lk * 2 * E:
+        raise ValueError(f"cross_attention_fwd: q {tuple(q.shape)} kv {tuple(kv.shape)} vs B={B} Lq={Lq} Lk={Lk} H={H}")
+    out = torch.empty((B * Lq, E), dtype=torch.float32, device=q.device)
+    lse = torch.empty((B, H, Lq), dtype=torch.float32, device=q.device)
+    _lib.check(lib.dclip_cross_attention_fwd(q.data_ptr(), kv.data_ptr(), out.data_ptr(), lse.data_ptr(), B, Lq, Lk, H,
+                                             _stream()), "cross_attention_fwd")
+    return out, lse
+
+
+def cross_attention_bwd(q, kv, out, dout, lse, B: int, Lq: int, Lk: int, H: int):
+    lib = _lib.load()
+    for n, t in (("q", q), ("kv", kv), ("out", out), ("dout", dout), ("lse", lse)):
+        _f32(t, n)
+    E = H * 64
+    if q.numel() != B * Lq * E or kv.numel() != B * Lk * 2 * E or out.numel() != q.numel() \
+            or dout.numel() != q.numel() or lse.numel() != B * H * Lq:
+        raise ValueError("cross_attention_bwd: shape mismatch")
+    dq = torch.empty_like(q)
+    dkv = torch.empty_like(kv)
+    delta = torch.empty((B * H * Lq,), dtype=torch.float32, device=q.device)
+    _lib.check(lib.dclip_cross_attention_bwd(q.data_ptr(), kv.data_ptr(), out.data_ptr(), dout.data_ptr(),
+                                             lse.data_ptr(), dq.data_ptr(), dkv.data_ptr(), delta.data_ptr(), B, Lq, Lk,
+                                             H, _stream()), "cross_attention_bwd")
+    return dq, dkv
+
+
+def aggregation_fwd(x, temperature: float = 2.0, out=None, out_scale: float = 1.0, accumulate: bool = False):
+    lib = _lib.load()
+    _f32(x, "x")
+    B, L, E = x.shape
+    if out is None:
+        out = torch.empty((B, E), dtype=torch.float32, device=x.device)
+        accumulate = False
+    _f32(out, "out")
+    w = torch.empty((B, L), dtype=torch.float32, device=x.device)
+    _lib.check(lib.dclip_aggregation_fwd(x.data_ptr(), out.data_ptr(), w.data_ptr(), B, L, E, float(temperature),
+                                         float(out_scale), int(accumulate), _stream()), "aggregation_fwd")
+    return out, w
+
+
+def aggregation_bwd(x, w, dout, temperature: float = 2.0, out_scale: float = 1.0):
+    lib = _lib.load()
+    _f32(x, "x"), _f32(w, "weights"), _f32(dout, "dout")
+    B, L, E = x.shape
+    if tuple(w.shape) != (B, L) or tuple(dout.shape) != (B, E):
+        raise ValueError("aggregation_bwd: shape mismatch")
+    dx = torch.empty_like(x)
+    _lib.check(lib.dclip_aggregation_bwd(x.data_ptr(), w.data_ptr(), dout.data_ptr(), dx.data_ptr(), B, L, E,
+                                         float(temperature), float(out_scale), _stream()), "aggregation_bwd")
+    return dx
+
+
+def pack_tokens(tokens, sentence, eos, Tmax: int):
+    lib = _lib.load()
+    _f32(tokens, "tokens"), _f32(sentence, "sentence")
+    B, T, Pd = tokens.shape
+    _idx(eos, B)
+    if tuple(sentence.shape) != (B, Pd) or not (0 < Tmax <= T):
+        raise ValueError("pack_tokens: shape mismatch")
+    out = torch.empty((B, Tmax, Pd), dtype=torch.float32, device=tokens.device)
+    _lib.check(lib.dclip_pack_tokens(tokens.data_ptr(), sentence.data_ptr(), eos.data_ptr(), out.data_ptr(), B, T, Tmax,
+                                     Pd, _stream()), "pack_tokens")
+    return out
+
+
+def mask_rows(x, count):
+    lib = _lib.load()
+    _f32(x, "x")
+    B, R, E = x.shape
+    _idx(count, B)
+    _lib.check(lib.dclip_mask_rows(x.data_ptr(), count.data_ptr(), B, R, E, _stream()), "mask_rows")
+    return x
+
+
 def axpby(x, y, a: float, b: float):
     """y = a*x + b*y (in place on y)."""
     lib = _lib.load()

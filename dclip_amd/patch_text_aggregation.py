@@ -1,0 +1,355 @@
+"""The meta-teacher: `CrossModalAttention` and `PatchTextAggregation`, same names, constructor arguments,
+methods and checkpoint keys as training/patch_text_aggregation.py, on the HIP kernels.
+
+What is kept from the reference:
+  * `CrossModalAttention(embed_dim, num_heads)`: two packed-projection multi-head attentions and two LayerNorms;
+    `state_dict()` holds exactly the 12 tensors `{text_to_image,image_to_text}.{in_proj_weight,in_proj_bias,
+    out_proj.weight,out_proj.bias}`, `{norm_text,norm_image}.{weight,bias}`.
+  * both directions attend from the ORIGINAL inputs; no key_padding_mask — zero-padded rows are attended,
+    LayerNorm'd and pooled (:33,:42,:555-620).
+  * `aggregation`: cosine-to-mean softmax pooling with temperature 2.0 (:243-265); final 0.5/0.5 mix (:647).
+  * region crops go to the CLIP vision tower in [0,1] without mean/std (training/image_tokenizer.py:28-32; N5).
+  * tokenizers are plain objects, not nn.Modules, so the teacher checkpoint contains only `cross_modal_attention.*`.
+
+What is deliberately different: the per-sample Python loop (:297-553) is replaced by ONE batched frozen vision
+forward over all regions and ONE batched frozen text forward that yields token-level and sentence embeddings
+together; the KNN / projection tokenizer (disabled when its paths are empty, :78-96) and YOLO detection are out of
+scope — boxes / region crops are inputs.
+"""
+from __future__ import annotations
+
+import math
+import os
+from typing import List, Optional, Sequence
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .clip_model import HipCLIPModel, _Affine
+
+
+# ------------------------------------------------------------------------------------------------ cross-modal block
+
+class _PackedMHA(nn.Module):
+    """Parameter holder with nn.MultiheadAttention's names and default initialisation."""
+
+    def __init__(self, embed_dim: int):
+        super().__init__()
+        e = embed_dim
+        self.in_proj_weight = nn.Parameter(torch.empty(3 * e, e))
+        self.in_proj_bias = nn.Parameter(torch.zeros(3 * e))
+        self.out_proj = _Affine((e, e))
+        nn.init.xavier_uniform_(self.in_proj_weight)
+        nn.init.kaiming_uniform_(self.out_proj.weight, a=math.sqrt(5))
+
+
+def _mha_dir_fwd(xq, xkv, B, Lq, Lk, E, H, in_w, in_b, out_w, out_b, ln_w, ln_b):
+    q = ops.gemm(xq, in_w[:E], ops.LAYOUT_NT, bias=in_b[:E])
+    kv = ops.gemm(xkv, in_w[E:], ops.LAYOUT_NT, bias=in_b[E:])
+    a, lse = ops.cross_attention_fwd(q, kv, B, Lq, Lk, H)
+    pre = ops.gemm(a, out_w, ops.LAYOUT_NT, bias=out_b, residual=xq)
+    y, mean, rstd = ops.layernorm_fwd(pre, ln_w, ln_b, 1e-5)
+    return y, (q, kv, a, lse, pre, mean, rstd)
+
+
+def _mha_dir_bwd(dy, xq, xkv, saved, B, Lq, Lk, E, H, in_w, out_w, ln_w, need_x: bool):
+    q, kv, a, lse, pre, mean, rstd = saved
+    dpre, d_ln_w, d_ln_b = ops.layernorm_bwd(dy, pre, ln_w, mean, rstd)
+    d_out_w = ops.gemm(dpre, a, ops.LAYOUT_TN)
+    d_out_b = ops.colsum(dpre)
+    da = ops.gemm(dpre, out_w, ops.LAYOUT_NN)
+    dq, dkv = ops.cross_attention_bwd(q, kv, a, da, lse, B, Lq, Lk, H)
+    d_in_w = torch.empty_like(in_w)
+    d_in_b = torch.empty((3 * E,), dtype=torch.float32, device=in_w.device)
+    ops.gemm(dq, xq, ops.LAYOUT_TN, out=d_in_w[:E])
+    ops.gemm(dkv, xkv, ops.LAYOUT_TN, out=d_in_w[E:])
+    ops.colsum(dq, out=d_in_b[:E])
+    ops.colsum(dkv, out=d_in_b[E:])
+    dxq = dxkv = None
+    if need_x:
+        dxq = ops.gemm(dq, in_w[:E], ops.LAYOUT_NN, residual=dpre)
+        dxkv = ops.gemm(dkv, in_w[E:], ops.LAYOUT_NN)
+    return (d_in_w, d_in_b, d_out_w, d_out_b, d_ln_w, d_ln_b), dxq, dxkv
+
+
+class CrossModalFn(torch.autograd.Function):
+    """(text [B,T,E], patches [B,R,E]) -> (LN(text + MHA(text <- patches)), LN(patches + MHA(patches <- text)))."""
+
+    @staticmethod
+    def forward(ctx, text, patches, heads, *params):
+        (t_in_w, t_in_b, t_out_w, t_out_b, i_in_w, i_in_b, i_out_w, i_out_b, nt_w, nt_b, ni_w, ni_b) = \
+            [p.detach().contiguous() for p in params]
+        B, T, E = text.shape
+        R = patches.shape[1]
+        t2 = text.detach().float().contiguous().view(B * T, E)
+        p2 = patches.detach().float().contiguous().view(B * R, E)
+        t_out, sv_t = _mha_dir_fwd(t2, p2, B, T, R, E, heads, t_in_w, t_in_b, t_out_w, t_out_b, nt_w, nt_b)
+        i_out, sv_i = _mha_dir_fwd(p2, t2, B, R, T, E, heads, i_in_w, i_in_b, i_out_w, i_out_b, ni_w, ni_b)
+        if any(ctx.needs_input_grad):
+            ctx.saved = (t2, p2, sv_t, sv_i, (t_in_w, t_out_w, i_in_w, i_out_w, nt_w, ni_w))
+        ctx.dims = (B, T, R, E, heads)
+        return t_out.view(B, T, E), i_out.view(B, R, E)
+
+    @staticmethod
+    def backward(ctx, d_t, d_i):
+        B, T, R, E, H = ctx.dims
+        t2, p2, sv_t, sv_i, (t_in_w, t_out_w, i_in_w, i_out_w, nt_w, ni_w) = ctx.saved
+        need_x = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
+        d_t = d_t.contiguous().view(B * T, E)
+        d_i = d_i.contiguous().view(B * R, E)
+        gt, dxq_t, dxkv_t = _mha_dir_bwd(d_t, t2, p2, sv_t, B, T, R, E, H, t_in_w, t_out_w, nt_w, need_x)
+        gi, dxq_i, dxkv_i = _mha_dir_bwd(d_i, p2, t2, sv_i, B, R, T, E, H, i_in_w, i_out_w, ni_w, need_x)
+        d_text = d_patch = None
+        if need_x:
+            d_text = ops.axpby(dxkv_i, dxq_t, 1.0, 1.0).view(B, T, E)
+            d_patch = ops.axpby(dxkv_t, dxq_i, 1.0, 1.0).view(B, R, E)
+        # parameter order: t.{in_w,in_b,out_w,out_b}, i.{...}, norm_text.{w,b}, norm_image.{w,b}
+        return (d_text, d_patch, None, gt[0], gt[1], gt[2], gt[3], gi[0], gi[1], gi[2], gi[3], gt[4], gt[5], gi[4], gi[5])
+
+
+class CrossModalAttention(nn.Module):
+    def __init__(self, embed_dim, num_heads):
+        super().__init__()
+        if embed_dim % num_heads or embed_dim // num_heads != 64:
+            raise ValueError("the HIP attention kernel is built for head_dim 64 (embed_dim / num_heads)")
+        self.embed_dim, self.num_heads = embed_dim, num_heads
+        self.text_to_image = _PackedMHA(embed_dim)
+        self.image_to_text = _PackedMHA(embed_dim)
+        self.norm_text = _Affine((embed_dim,), ones=True)
+        self.norm_image = _Affine((embed_dim,), ones=True)
+
+    def _params(self):
+        t, i = self.text_to_image, self.image_to_text
+        return (t.in_proj_weight, t.in_proj_bias, t.out_proj.weight, t.out_proj.bias,
+                i.in_proj_weight, i.in_proj_bias, i.out_proj.weight, i.out_proj.bias,
+                self.norm_text.weight, self.norm_text.bias, self.norm_image.weight, self.norm_image.bias)
+
+    def forward(self, text_embedding, image_embedding):
+        """Bidirectional attention between text and image tokens (training/patch_text_aggregation.py:21-46)."""
+        return CrossModalFn.apply(text_embedding, image_embedding, self.num_heads, *self._params())
+
+
+class GlobalPoolFn(torch.autograd.Function):
+    """0.5 * aggregation(attended_text) + 0.5 * aggregation(attended_image) (:643-647), one kernel per side."""
+
+    @staticmethod
+    def forward(ctx, at, ai, temperature):
+        at, ai = at.detach().contiguous(), ai.detach().contiguous()
+        out, wt = ops.aggregation_fwd(at, temperature, out_scale=0.5)
+        _, wi = ops.aggregation_fwd(ai, temperature, out=out, out_scale=0.5, accumulate=True)
+        ctx.save_for_backward(at, ai, wt, wi)
+        ctx.temperature = temperature
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        at, ai, wt, wi = ctx.saved_tensors
+        d_out = d_out.contiguous()
+        return (ops.aggregation_bwd(at, wt, d_out, ctx.temperature, 0.5),
+                ops.aggregation_bwd(ai, wi, d_out, ctx.temperature, 0.5), None)
+
+
+class AggregationFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, temperature):
+        x = x.detach().contiguous()
+        out, w = ops.aggregation_fwd(x, temperature)
+        ctx.save_for_backward(x, w)
+        ctx.temperature = temperature
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        x, w = ctx.saved_tensors
+        return ops.aggregation_bwd(x, w, d_out.contiguous(), ctx.temperature, 1.0), None
+
+
+# ------------------------------------------------------------------------------------------------ tokenizers
+
+class CLIPTextTokenizer:
+    """Frozen teacher text side (training/text_tokenizer.py).  `model` is a HipCLIPModel; `tokenizer` an HF
+    CLIPTokenizer loaded from a LOCAL path, or None when callers pass token ids (synthetic configs).
+    The BERT / GloVe word-complexity machinery of the reference (:26-143) is never called on this path."""
+
+    def __init__(self, model: HipCLIPModel, tokenizer=None, max_chunk_size: int = 77):
+        self.model = model
+        self.tokenizer = tokenizer
+        self.max_chunk_size = max_chunk_size
+
+    @property
+    def device(self):
+        return next(self.model.parameters()).device
+
+    def _ids(self, text) -> torch.Tensor:
+        if isinstance(text, torch.Tensor):
+            ids = text if text.dim() == 2 else text.unsqueeze(0)
+        else:
+            if self.tokenizer is None:
+                raise RuntimeError("caption strings need a CLIPTokenizer (load one from a local path); "
+                                   "or pass token ids")
+            ids = self.tokenizer(text, return_tensors="pt", padding=True, truncation=True, max_length=77).input_ids
+        return ids.to(self.device).long().contiguous()
+
+    @torch.no_grad()
+    def token_level_ids(self, input_ids: torch.Tensor):
+        """(sentence [B,P], tokens [B,T,P], eos [B]) from one frozen forward."""
+        return self.model.text_token_level(self._ids(input_ids))
+
+    @torch.no_grad()
+    def aggregate_text_ids(self, input_ids: torch.Tensor) -> torch.Tensor:
+        return self.token_level_ids(input_ids)[0]
+
+    @torch.no_grad()
+    def get_embeddings(self, text, return_token_level=True) -> List[torch.Tensor]:
+        """:171-216 — list of word-token embeddings (BOS/EOS dropped), or [sentence embedding]."""
+        sent, tokens, eos = self.token_level_ids(self._ids(text)[:1])
+        n = max(int(eos[0]) - 1, 0)
+        if return_token_level and n > 0:
+            return [tokens[0, 1 + i] for i in range(n)]
+        return [sent[0]]
+
+    @torch.no_grad()
+    def aggregate_text(self, text) -> torch.Tensor:
+        """:220-235 — the sentence-level embedding [E]."""
+        return self.aggregate_text_ids(self._ids(text)[:1])[0]
+
+
+class CLIPPatchTokenizer:
+    """Frozen teacher region side (training/image_tokenizer.py:19-124) without the detector: boxes are inputs."""
+
+    def __init__(self, clip_model: HipCLIPModel):
+        self.clip_model = clip_model
+
+    @property
+    def device(self):
+        return next(self.clip_model.parameters()).device
+
+    def get_weighted_bounding_boxes(self, image_path):
+        raise NotImplementedError("YOLO detection is outside the distillation step: pass cached boxes "
+                                  "(weighted_boxes_batch) as the reference's training loop does")
+
+    get_weighted_bounding_boxes_batch = get_weighted_bounding_boxes
+
+    def patch_transform(self, pil_patch) -> torch.Tensor:
+        """Resize((S,S)) + ToTensor(): bilinear PIL resize, HWC uint8 -> CHW float in [0,1], no mean/std (:28-32)."""
+        import numpy as np
+        from PIL import Image
+        s = self.clip_model.config.vision.image_size
+        arr = np.asarray(pil_patch.convert("RGB").resize((s, s), Image.BILINEAR), dtype=np.float32) / 255.0
+        return torch.from_numpy(arr).permute(2, 0, 1).contiguous()
+
+    @torch.no_grad()
+    def encode_regions(self, regions: torch.Tensor) -> torch.Tensor:
+        """[N,3,S,S] in [0,1] -> [N,E] (one batched frozen forward)."""
+        return self.clip_model.get_image_features(pixel_values=regions.to(self.device).float())
+
+    @torch.no_grad()
+    def encode_weighted_bounding_boxes(self, image, weighted_boxes, full_resolution=False):
+        """:86-124 — list of (clip_embedding, confidence)."""
+        if full_resolution:
+            raise NotImplementedError("full_resolution crops are rejected by CLIP without interpolate_pos_encoding "
+                                      "(hf:modeling_clip.py:204-207); the reference never enables it (SURVEY §5)")
+        if not weighted_boxes:
+            return []
+        crops = torch.stack([self.patch_transform(image.crop(box)) for box, _ in weighted_boxes])
+        embs = self.encode_regions(crops)
+        return [(e, conf) for e, (_, conf) in zip(embs, weighted_boxes)]
+
+
+# ------------------------------------------------------------------------------------------------ the teacher
+
+class PatchTextAggregation(nn.Module):
+    def __init__(self, embed_dim=512, num_heads=8, similarity_threshold=0.85, projection_model_path=None,
+                 faiss_index_path=None, embeddings_json_path=None, clip_model: Optional[HipCLIPModel] = None,
+                 tokenizer=None):
+        super().__init__()
+        if all([projection_model_path, faiss_index_path, embeddings_json_path]):
+            raise NotImplementedError("the KNN + projection tokenizer is outside the distillation step "
+                                      "(README.md:21: leave these paths blank)")
+        if clip_model is None:
+            raise ValueError("pass clip_model (a HipCLIPModel holding the teacher's CLIP towers); nothing is "
+                             "downloaded by name here")
+        self.embed_dim = embed_dim
+        self.similarity_threshold = similarity_threshold
+        # plain attributes on purpose: the towers must not enter teacher.state_dict()
+        object.__setattr__(self, "_clip", clip_model)
+        self.text_tokenizer = CLIPTextTokenizer(clip_model, tokenizer)
+        self.patch_tokenizer = CLIPPatchTokenizer(clip_model)
+        self.cross_modal_attention = CrossModalAttention(embed_dim, num_heads)
+        self.knn_cache = {}
+        self.use_knn_projection = False
+        self.advanced_tokenizer = None
+        self.full_resolution = False
+
+    @property
+    def device(self):
+        return self.cross_modal_attention.norm_text.weight.device
+
+    def shares_text_tower_with(self, student: HipCLIPModel) -> bool:
+        """True when the teacher's frozen text tower IS the (frozen) student text tower: one forward serves both."""
+        return self._clip is student and not any(p.requires_grad for p in student.text_model.parameters()) \
+            and not student.text_projection.weight.requires_grad
+
+    def load_caches(self, knn_cache_path=None):
+        """:104-124 — the KNN cache only feeds the (out-of-scope) KNN tokenizer; kept so callers do not break."""
+        self.knn_cache = {}
+        return self
+
+    def cross_attention(self, text_embedding, patch_embedding):
+        return self.cross_modal_attention(text_embedding, patch_embedding)
+
+    def aggregation(self, attended_text, temperature=2.0):
+        return AggregationFn.apply(attended_text, temperature)
+
+    # ---- tensor-in variant (synthetic configs, and the body of the path-based method)
+    def compute_global_embedding_tensors(self, regions: torch.Tensor, input_ids: torch.Tensor,
+                                         region_counts: Optional[torch.Tensor] = None,
+                                         max_tokens: Optional[int] = None) -> torch.Tensor:
+        """regions [B,R,3,S,S] in [0,1] (rows >= region_counts[b] ignored), input_ids [B,T] -> [B,E].
+        Gradients flow only into cross_modal_attention (the towers run frozen, as in the reference:
+        training/image_tokenizer.py:119, training/text_tokenizer.py:185)."""
+        dev = self.device
+        B, R = regions.shape[:2]
+        with torch.no_grad():
+            emb = self.patch_tokenizer.encode_regions(regions.reshape(B * R, *regions.shape[2:])).view(B, R, -1)
+            if region_counts is not None:
+                counts = region_counts.to(dev).to(torch.int32).contiguous()
+                rmax = max(int(region_counts.max()), 1)        # an image without boxes keeps ONE zero row (:489-491)
+                emb = ops.mask_rows(emb.contiguous(), counts)[:, :rmax].contiguous()
+            sent, tokens, eos = self.text_tokenizer.token_level_ids(input_ids)
+            if max_tokens is None:
+                max_tokens = max(int(eos.max()) - 1, 1)       # host sync; pass max_tokens to avoid it
+            text = ops.pack_tokens(tokens.contiguous(), sent, eos, max_tokens)
+        return self.global_embedding_from_tokens(text, emb)
+
+    def global_embedding_from_tokens(self, text: torch.Tensor, patches: torch.Tensor) -> torch.Tensor:
+        """[B,Tmax,E], [B,Rmax,E] (zero-padded) -> [B,E]: :634-647."""
+        at, ai = self.cross_modal_attention(text, patches)
+        return GlobalPoolFn.apply(at, ai, 2.0)
+
+    # ---- the reference's path-based signature
+    def compute_global_embedding_batch(self, image_paths, texts, weighted_boxes_batch=None):
+        """:268-656 with cached boxes: crops are cut on the host (PIL) and everything after runs batched on the GPU."""
+        from PIL import Image
+        if weighted_boxes_batch is None:
+            raise NotImplementedError("no detector here: pass weighted_boxes_batch (the reference's loader does)")
+        if isinstance(weighted_boxes_batch, list):
+            weighted_boxes_batch = dict(zip(image_paths, weighted_boxes_batch))
+        s = self._clip.config.vision.image_size
+        crops: List[List[torch.Tensor]] = []
+        for path in image_paths:
+            try:
+                image = Image.open(path).convert("RGB")
+            except Exception:
+                image = Image.new("RGB", (224, 224))
+            crops.append([self.patch_tokenizer.patch_transform(image.crop(box))
+                          for box, _ in weighted_boxes_batch.get(path, [])])
+        counts = torch.tensor([len(c) for c in crops], dtype=torch.int32)
+        rmax = max(int(counts.max()), 1)
+        regions = torch.zeros(len(crops), rmax, 3, s, s)
+        for b, c in enumerate(crops):
+            if c:
+                regions[b, :len(c)] = torch.stack(c)
+        ids = self.text_tokenizer._ids(list(texts))
+        return self.compute_global_embedding_tensors(regions.to(self.device), ids, counts)

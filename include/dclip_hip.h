@@ -175,6 +175,34 @@ int dclip_sub_reduce(const float* a, const float* b, float* out, int n, float sc
                      void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Meta-teacher tail (training/patch_text_aggregation.py).
+ * cross_attention: softmax(Q K^T / 8) V with separate query and key/value sequences — the core of
+ *   nn.MultiheadAttention(E, heads) as called at :33 and :42 (head_dim 64, dropout 0, no masks: zero-padded
+ *   rows ARE attended).  q [B*Lq, H*64]; kv [B*Lk, 2*H*64] = [k | v] (the packed in_proj rows
+ *   E..3E applied in one GEMM); out [B*Lq, H*64]; lse [B,H,Lq].  Same MFMA kernels as dclip_attention_*.
+ *   _bwd returns dq [B*Lq, E] and dkv [B*Lk, 2E]; delta is scratch [B*H*Lq].
+ * aggregation: m = mean_l x_l; s_l = <x_l,m> / (max(|x_l|,1e-8) max(|m|,1e-8)); w = softmax(s / temperature);
+ *   out[b,:] (+)= out_scale * sum_l w_l x_l   (:243-265; the 0.5/0.5 mix of :647 is out_scale + accumulate).
+ *   weights [B,L] are kept for _bwd, which returns d x for d out (already including out_scale).  L <= 96.
+ * pack_tokens: the token filter of training/text_tokenizer.py:195-213 plus the zero padding of
+ *   patch_text_aggregation.py:606-620 on device: out[b,i,:] = tokens[b,1+i,:] for i < eos[b]-1, zero beyond;
+ *   a caption with no word tokens contributes its sentence embedding as row 0.
+ * mask_rows: x[b,r,:] = 0 for r >= count[b]  (zero padding of region embeddings, :555-581).
+ */
+int dclip_cross_attention_fwd(const float* q, const float* kv, float* out, float* lse, int B, int Lq, int Lk,
+                              int H, void* stream);
+int dclip_cross_attention_bwd(const float* q, const float* kv, const float* out, const float* dout,
+                              const float* lse, float* dq, float* dkv, float* delta, int B, int Lq, int Lk,
+                              int H, void* stream);
+int dclip_aggregation_fwd(const float* x, float* out, float* weights, int B, int L, int E, float temperature,
+                          float out_scale, int accumulate, void* stream);
+int dclip_aggregation_bwd(const float* x, const float* weights, const float* dout, float* dx, int B, int L,
+                          int E, float temperature, float out_scale, void* stream);
+int dclip_pack_tokens(const float* tokens, const float* sentence, const int32_t* eos, float* out, int B, int T,
+                      int Tmax, int P, void* stream);
+int dclip_mask_rows(float* x, const int32_t* count, int B, int R, int E, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Small elementwise helpers used between the ops above (all fp32, 16-byte vectorised).
  */
 int dclip_axpby(const float* x, float* y, float a, float b, size_t n, void* stream); /* y = a*x + b*y */

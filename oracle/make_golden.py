@@ -350,7 +350,7 @@ def gen_teacher_glue(pta, tt, it):
     nn.Module.__init__(teacher)
     teacher.embed_dim, teacher.device = E, torch.device("cpu")
     teacher.text_tokenizer, teacher.patch_tokenizer = text_tok, patch_tok
-    teacher.cross_modal_attention = pta.CrossModalAttention(E, 2)
+    teacher.cross_modal_attention = pta.CrossModalAttention(E, E // 64)      # head_dim 64, as in every real config
     teacher.cross_modal_attention.load_state_dict(cmsd)
     teacher.knn_cache, teacher.use_knn_projection, teacher.advanced_tokenizer = {}, False, None
     teacher.full_resolution = False

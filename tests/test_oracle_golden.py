@@ -199,7 +199,7 @@ def test_teacher_glue(golden):
         embs = [O.vision_tower(sd, regions[b, :int(n_regions[b])], cfg.vision) if n_regions[b] > 0
                 else torch.zeros(0, cfg.projection_dim) for b in range(ids.shape[0])]
         patches = O.pad_regions(embs, cfg.projection_dim)
-        glob = O.global_embedding(cm, toks, patches, heads=2)
+        glob = O.global_embedding(cm, toks, patches, heads=cfg.projection_dim // 64)
     close(glob, g["global"], rtol=1e-4, atol=1e-5)
 
 
