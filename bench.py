@@ -1,0 +1,260 @@
+#!/usr/bin/env python3
+"""DCLIP distillation-step benchmark (BASELINE.json metric: distill-step images/sec at ViT-B/32 bs=256).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one synthetic batch of 256 image-caption pairs per GPU
+(BASELINE config c2): student ViT-B/32 forward + backward (all vision parameters trainable), frozen text tower
+forward (shared by student and teacher: north_star regime), cosine distillation losses against a
+given teacher image embedding, symmetric InfoNCE over the (all-gathered) similarity matrix, gradient all-reduce
+for N > 1, and the AdamW update.  Inputs are resident in HBM before the timed region.  fp32 throughout.
+
+Prints ONE JSON line on rank 0 (see README / DESIGN.md for the field meanings).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+from dclip_amd import config as dcfg, synth  # noqa: E402
+
+PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X dense fp32 matrix peak (MI355X_MICROARCH.md, chip-level table)
+
+
+def vision_fwd_flops(v) -> float:
+    S, D, L = v.seq_len, v.hidden_size, v.num_hidden_layers
+    per_layer = 2.0 * S * D * (3 * D) + 2.0 * S * D * D + 2.0 * 2.0 * S * D * v.intermediate_size + 4.0 * S * S * D
+    return L * per_layer + 2.0 * (S - 1) * v.patch_dim * D
+
+
+def text_fwd_flops(t, T) -> float:
+    D, L = t.hidden_size, t.num_hidden_layers
+    per_layer = 2.0 * T * D * (3 * D) + 2.0 * T * D * D + 2.0 * 2.0 * T * D * t.intermediate_size + 4.0 * T * T * D
+    return L * per_layer
+
+
+def step_flops_per_image(cfg, T) -> float:
+    """Algorithmic FLOPs of one distill step per image, north_star regime: 3 x F_vis (fwd + dgrad + wgrad) + 1 x
+    F_txt (frozen) + projections (32.4 GFLOP/img for ViT-B/32)."""
+    fv = vision_fwd_flops(cfg.vision) + 2.0 * cfg.vision.hidden_size * cfg.projection_dim
+    ft = text_fwd_flops(cfg.text, T) + 2.0 * cfg.text.hidden_size * cfg.projection_dim
+    return 3.0 * fv + ft
+
+
+class GemmTimer:
+    """HIP events around every dclip_gemm_f32 launch, on the stream the kernels are launched on (torch's current
+    stream — torch.cuda.Event records there).  Sum(flops) / Sum(elapsed) over the timed region is the roofline
+    figure for the dominant kernel."""
+
+    def __init__(self):
+        self.records = []
+        self.enabled = False
+
+    def install(self):
+        from dclip_amd import ops
+        inner = ops.gemm
+        timer = self
+
+        def timed_gemm(a, b, layout, **kw):
+            if not timer.enabled:
+                return inner(a, b, layout, **kw)
+            M, K = a.shape if layout & ops.A_KMAJOR else a.shape[::-1]
+            N = b.shape[0] if layout & ops.B_KMAJOR else b.shape[1]
+            e0 = torch.cuda.Event(enable_timing=True)
+            e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = inner(a, b, layout, **kw)
+            e1.record()
+            timer.records.append((2.0 * M * N * K, e0, e1))
+            return out
+
+        ops.gemm = timed_gemm
+
+    def summary(self):
+        flops = sum(r[0] for r in self.records)
+        ms = sum(r[1].elapsed_time(r[2]) for r in self.records)
+        return flops, ms, len(self.records)
+
+
+def cpu_baseline(seconds: float = 12.0):
+    """The reference's step arithmetic restated on the CPU (oracle/dclip_oracle.py, pinned to the reference's own
+    outputs by tests/golden): BASELINE config c1 — ViT-B/32 + text tower, bs=8, forward + backward — timed on the
+    host cores for a bounded sample."""
+    from oracle import dclip_oracle as O
+    cores = max(1, min(os.cpu_count() or 1, len(os.sched_getaffinity(0)), 32))
+    torch.set_num_threads(cores)
+    cfg = dcfg.vit_b32()
+    sd = synth.synth_clip_state_dict(cfg, seed=0)
+    p = {k: v.clone().requires_grad_(v.is_floating_point() and v.dim() > 0) for k, v in sd.items()}
+    B = 8
+    pix = synth.synth_pixel_values(B, cfg.vision, seed=0)
+    ids = synth.synth_input_ids(B, cfg.text, seed=3)
+    t_img = synth.synth_embeddings(B, cfg.projection_dim, seed=1)
+
+    def one():
+        out = O.distill_step(p, cfg, pix, ids, t_img)
+        out["loss"].backward()
+        for v in p.values():
+            v.grad = None
+
+    one()
+    n, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < seconds or n < 2:
+        one()
+        n += 1
+    dt = time.perf_counter() - t0
+    return {"value": round(B * n / dt, 3), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"config c1: ViT-B/32 + text tower, bs={B}, fwd+bwd, {n} steps in {dt:.1f} s "
+                      f"(oracle/dclip_oracle.py, torch {torch.__version__} CPU, all towers trainable as in the "
+                      f"reference's as-written step)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=256, help="per-GPU batch (weak scaling)")
+    ap.add_argument("--model", default="ViT-B/32", choices=list(dcfg.NAMED))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-optimizer", action="store_true", help="time forward+backward only")
+    ap.add_argument("--no-gemm-events", action="store_true", help="do not bracket GEMM launches with HIP events")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit(f"--gpus {args.gpus} needs one process per GPU: launch with "
+                             f"python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py ...")
+    assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    from dclip_amd import dist as ddist
+    group = ddist.init_from_env("nccl") if world > 1 else None
+
+    from dclip_amd.clip_model import from_hf_state_dict
+    from dclip_amd.CLIP_image_distillation import CLIPImageDistillation
+    from dclip_amd.patch_text_aggregation import PatchTextAggregation
+    from dclip_amd import optim
+
+    cfg = dcfg.NAMED[args.model]()
+    student = from_hf_state_dict(cfg, synth.synth_clip_state_dict(cfg, seed=0), device=dev)   # same init on all ranks
+    teacher = PatchTextAggregation(embed_dim=cfg.projection_dim, num_heads=cfg.projection_dim // 64,
+                                   clip_model=student).to(dev)
+    hp = argparse.Namespace(learning_rate=1e-6, warmup_steps=0, total_steps=10 ** 6, train_batch_size=args.batch,
+                            eval_batch_size=args.batch)
+    module = CLIPImageDistillation(hp, student, None, teacher=teacher, freeze_mode="north_star",
+                                   process_group=group).to(dev)
+    trainable = [p for p in module.parameters() if p.requires_grad]
+    opt = None if args.no_optimizer else optim.FusedAdamW(trainable, lr=hp.learning_rate, max_grad_norm=0.5)
+    sync = ddist.GradSync(trainable, group) if world > 1 else None
+
+    B, T = args.batch, cfg.text.max_position_embeddings
+    batch = {                                                     # resident in HBM before the timed region
+        "pixel_values": synth.synth_pixel_values(B, cfg.vision, seed=rank).to(dev),
+        "input_ids": synth.synth_input_ids(B, cfg.text, seed=100 + rank).to(dev),
+        "teacher_image_emb": synth.synth_embeddings(B, cfg.projection_dim, seed=1000 + rank).to(dev),
+    }
+
+    timer = GemmTimer()
+    if not args.no_gemm_events:
+        timer.install()
+
+    def step():
+        loss = module.training_step(batch)      # N > 1: this rank's share of the global loss (dist.py)
+        loss.backward()
+        if sync is not None:
+            sync.reduce()
+        if opt is not None:
+            opt.step()
+            opt.zero_grad(set_to_none=True)
+        else:
+            for p in trainable:
+                p.grad = None
+        return loss
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    timer.enabled = True
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        last = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    timer.enabled = False
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+
+    if rank == 0:
+        ms_per_step = elapsed * 1e3 / args.steps
+        value = world * B * args.steps / elapsed
+        step_flops = step_flops_per_image(cfg, T) * B
+        gflops, gms, glaunches = timer.summary() if not args.no_gemm_events else (0.0, 0.0, 0)
+        achieved = gflops / (gms * 1e-3) / 1e12 if gms > 0 else None
+        traffic = None
+        pmc = os.path.join(REPO, "profiles", "gemm_traffic.json")
+        if os.path.exists(pmc):
+            traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+        line = {
+            "metric": "distill-step images/sec at ViT-B/32 bs=256",
+            "value": round(value, 2),
+            "unit": "images/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"BASELINE config c2: {cfg.name} distill step, bs={B}/GPU, 224x224 + {T}-token "
+                                   f"synthetic pairs, contrastive+cosine loss, fp32, vision trainable / text frozen "
+                                   f"(north_star regime), " + ("fwd+bwd only" if opt is None else "fwd+bwd + clip-norm 0.5 + AdamW"),
+                       "global_batch": world * B, "parallelism": f"dp{world}",
+                       "loss": float(last.detach())},
+            "roofline": {"bound": "mfma", "kernel": "gemm_f32_kernel (v_mfma_f32_32x32x2_f32)",
+                         "achieved": None if achieved is None else round(achieved, 2),
+                         "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": None if achieved is None else round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
+                         "traffic": traffic,
+                         "launches_per_step": glaunches // max(1, args.steps),
+                         "gemm_ms_per_step": round(gms / max(1, args.steps), 3),
+                         "gemm_flops_per_step": gflops / max(1, args.steps)},
+            "roofline_step": {"bound": "mfma", "achieved": round(step_flops / (ms_per_step * 1e-3) / 1e12, 2),
+                              "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                              "frac": round(step_flops / (ms_per_step * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                              "flops_per_image": step_flops_per_image(cfg, T)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

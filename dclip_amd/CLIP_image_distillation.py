@@ -140,7 +140,14 @@ class CLIPImageDistillation(LightningLikeModule):
                     teacher_text = self.teacher.text_tokenizer.aggregate_text_ids(tokens).float()
         loss_text = self.cosine_distillation_loss(student_text, teacher_text)
         contrastive = self.compute_contrastive_loss(student_image, student_text)
-        loss = loss_image + loss_text + 1.0 * contrastive
+        if self.process_group is None:
+            loss = loss_image + loss_text + 1.0 * contrastive
+        else:
+            # data parallel: return this rank's SHARE of the global loss (sum over ranks = the single-process value;
+            # `contrastive` already is a share), so SUM-reducing gradients over ranks is exact (dist.py)
+            from .dist import local_loss_for_backward
+            import torch.distributed as tdist
+            loss = local_loss_for_backward(loss_image, loss_text, contrastive, tdist.get_world_size(self.process_group))
         self.last_losses = {"loss_image": loss_image.detach(), "loss_text": loss_text.detach(),
                             "loss_contrastive": contrastive.detach()}
         self.log(log_name, loss.detach(), prog_bar=True, batch_size=getattr(self.hparams, bs_field, None))
@@ -157,7 +164,12 @@ class CLIPImageDistillation(LightningLikeModule):
         lr = getattr(self.hparams, "learning_rate", 2e-5)
         warm = getattr(self.hparams, "warmup_steps", 0)
         total = getattr(self.hparams, "total_steps", 1000)
-        optimizer = torch.optim.AdamW([p for p in self.parameters() if p.requires_grad], lr=lr)
+        params = [p for p in self.parameters() if p.requires_grad]
+        if params and params[0].is_cuda:
+            from .optim import FusedAdamW
+            optimizer = FusedAdamW(params, lr=lr)
+        else:           # CPU: checkpoint handling / tests only; no kernels run there
+            optimizer = torch.optim.AdamW(params, lr=lr)
 
         def lr_lambda(step: int):
             if step < warm:

@@ -52,6 +52,10 @@ SIGNATURES = {
     "dclip_aggregation_bwd": (I, [P, P, P, P, I, I, I, F, F, P]),
     "dclip_pack_tokens": (I, [P, P, P, P, I, I, I, I, P]),
     "dclip_mask_rows": (I, [P, P, I, I, I, P]),
+    "dclip_sumsq_blocks": (I, [Z]),
+    "dclip_sumsq_f32": (I, [P, Z, P, P]),
+    "dclip_clip_coef": (I, [P, I, F, P, P, P]),
+    "dclip_adamw_f32": (I, [P, P, P, P, Z, F, F, F, F, F, I, P, P]),
     "dclip_axpby": (I, [P, P, F, F, Z, P]),
     "dclip_fill": (I, [P, F, Z, P]),
 }

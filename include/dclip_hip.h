@@ -203,6 +203,22 @@ int dclip_pack_tokens(const float* tokens, const float* sentence, const int32_t*
 int dclip_mask_rows(float* x, const int32_t* count, int B, int R, int E, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Optimiser tail (pulled into the timed step).
+ * sumsq / clip_coef: global-norm clipping as torch.nn.utils.clip_grad_norm_ does it, which is what Lightning's
+ *   Trainer(gradient_clip_val=0.5) applies (training/CLIP_image_distill_training.py:41): each tensor writes
+ *   dclip_sumsq_blocks(n) partial sums; clip_coef reduces ALL partials to coef = min(1, max_norm/(norm+1e-6))
+ *   on the device (no host sync) and optionally returns the norm.
+ * adamw: torch.optim.AdamW update (training/CLIP_image_distillation.py:680; decoupled weight decay, bias
+ *   correction from the integer `step` >= 1); the gradient is multiplied by *grad_scale (device scalar, may be
+ *   NULL) first, which is where the clip coefficient goes.
+ */
+int dclip_sumsq_blocks(size_t n);
+int dclip_sumsq_f32(const float* x, size_t n, float* partial, void* stream);
+int dclip_clip_coef(const float* partial, int n, float max_norm, float* coef, float* norm_out, void* stream);
+int dclip_adamw_f32(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2,
+                    float eps, float weight_decay, int step, const float* grad_scale, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Small elementwise helpers used between the ops above (all fp32, 16-byte vectorised).
  */
 int dclip_axpby(const float* x, float* y, float a, float b, size_t n, void* stream); /* y = a*x + b*y */

@@ -279,3 +279,24 @@ def test_cosine_loss_against_golden(dev, golden):
     z, zt = torch.from_numpy(g["zero_row.img"]), torch.from_numpy(g["zero_row.txt"])
     loss_sum, _ = ops.cosine_loss_fwd(z.to(dev), zt.to(dev))
     assert abs(float(loss_sum) / 4 - float(g["zero_row.cos"])) < 1e-5
+
+
+# ---------------------------------------------------------------------------------- optimiser tail
+
+def test_fused_adamw_and_clip_match_torch(dev):
+    from dclip_amd.optim import FusedAdamW
+    shapes = [(768, 768), (2304,), (7,), (512, 3, 4, 4), ()]
+    ps = [torch.nn.Parameter(rnd(s, i) if s else torch.tensor(0.3)) for i, s in enumerate(shapes)]
+    mine = [torch.nn.Parameter(p.detach().clone().to(dev)) for p in ps]
+    ref_opt = torch.optim.AdamW(ps, lr=1e-2)
+    my_opt = FusedAdamW(mine, lr=1e-2, max_grad_norm=0.5)
+    for step in range(4):
+        for j, (p, q) in enumerate(zip(ps, mine)):
+            g = rnd(p.shape, 100 * step + j, 0.05) if p.dim() else torch.tensor(0.01 * (step + 1))
+            p.grad, q.grad = g.clone(), g.clone().to(dev)
+        norm = torch.nn.utils.clip_grad_norm_(ps, 0.5)
+        ref_opt.step()
+        my_opt.step()
+        assert abs(float(my_opt.last_grad_norm) - float(norm)) < 1e-5 * float(norm)
+    for p, q in zip(ps, mine):
+        assert relerr(q, p) < 1e-5 or float((q.cpu() - p).abs().max()) < 1e-7
