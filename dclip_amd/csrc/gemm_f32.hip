@@ -16,6 +16,7 @@
 // Workgroup ids are remapped so that the 8 XCDs each walk a contiguous band of row-tiles (A panel reuse in
 // that XCD's L2; B, the weight, is small and shared through the Infinity Cache).
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -103,121 +104,129 @@ __global__ void __launch_bounds__(256, 2) gemm_f32_kernel(GemmParams p) {
 
   f32x4 ra[A_CHUNKS], rb[B_CHUNKS];
 
+  // Branch-free staging: every lane always issues its 16-byte load from an address clamped into the operand
+  // (load_tile), and out-of-range elements are zeroed with selects only when the registers are written to LDS
+  // (store_tile), AFTER the MFMA block — so the loads' latency hides under the current tile's MFMAs.  (A per-load
+  // branch makes hipcc wrap each load in exec-mask control flow; a select right after the load makes it wait there.)
+  const int k_last4 = (p.K - 1) & ~3;  // start of the last (possibly partial) 4-chunk of a K-major row
   auto load_tile = [&](int kt) {
     const int k0 = kbeg + kt * BK;
 #pragma unroll
     for (int c = 0; c < A_CHUNKS; ++c) {
-      int id = tid + c * 256;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      const int id = tid + c * 256;
       if (A_KMAJOR) {  // rows of 8 chunks
-        int row = id >> 3, slot = id & 7;
-        int gm = m0 + row, gk = k0 + slot * 4;
-        if (gm < p.M && gk < kend) {
-          const float* src = p.A + (size_t)gm * p.lda + gk;
-          if (gk + 3 < kend) v = *reinterpret_cast<const f32x4*>(src);
-          else  // ragged K tail (K % 4 != 0): element-wise
-            for (int e = 0; e < 4; ++e) v[e] = (gk + e < kend) ? src[e] : 0.f;
-        }
+        const int gm = m0 + (id >> 3), gk = k0 + (id & 7) * 4;
+        ra[c] = *reinterpret_cast<const f32x4*>(p.A + (size_t)min(gm, p.M - 1) * p.lda + min(gk, k_last4));
       } else {  // [32][BM]: BM/4 chunks per k row
-        int kk = id / (BM / 4), c4 = id % (BM / 4);
-        int gk = k0 + kk, gm = m0 + c4 * 4;
-        if (gk < kend && gm < p.M) v = *reinterpret_cast<const f32x4*>(p.A + (size_t)gk * p.lda + gm);
+        const int gk = k0 + id / (BM / 4), gm = m0 + (id % (BM / 4)) * 4;
+        ra[c] = *reinterpret_cast<const f32x4*>(p.A + (size_t)min(gk, p.K - 1) * p.lda + min(gm, p.M - 4));
       }
-      ra[c] = v;
     }
 #pragma unroll
     for (int c = 0; c < B_CHUNKS; ++c) {
-      int id = tid + c * 256;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      const int id = tid + c * 256;
       if (B_KMAJOR) {
-        int row = id >> 3, slot = id & 7;
-        int gn = n0 + row, gk = k0 + slot * 4;
-        if (gn < p.N && gk < kend) {
-          const float* src = p.B + (size_t)gn * p.ldb + gk;
-          if (gk + 3 < kend) v = *reinterpret_cast<const f32x4*>(src);
-          else
-            for (int e = 0; e < 4; ++e) v[e] = (gk + e < kend) ? src[e] : 0.f;
-        }
+        const int gn = n0 + (id >> 3), gk = k0 + (id & 7) * 4;
+        rb[c] = *reinterpret_cast<const f32x4*>(p.B + (size_t)min(gn, p.N - 1) * p.ldb + min(gk, k_last4));
       } else {
-        int kk = id / (BN / 4), c4 = id % (BN / 4);
-        int gk = k0 + kk, gn = n0 + c4 * 4;
-        if (gk < kend && gn < p.N) v = *reinterpret_cast<const f32x4*>(p.B + (size_t)gk * p.ldb + gn);
+        const int gk = k0 + id / (BN / 4), gn = n0 + (id % (BN / 4)) * 4;
+        rb[c] = *reinterpret_cast<const f32x4*>(p.B + (size_t)min(gk, p.K - 1) * p.ldb + min(gn, p.N - 4));
       }
-      rb[c] = v;
     }
   };
 
-  auto store_tile = [&](int buf) {
+  auto store_tile = [&](int buf, int kt) {
+    const int k0 = kbeg + kt * BK;
     float* a = As + buf * BM * BK;
     float* b = Bs + buf * BN * BK;
 #pragma unroll
     for (int c = 0; c < A_CHUNKS; ++c) {
-      int id = tid + c * 256;
+      const int id = tid + c * 256;
+      f32x4 v = ra[c];
       if (A_KMAJOR) {
-        int row = id >> 3, slot = id & 7;
-        *reinterpret_cast<f32x4*>(a + row * BK + ((slot ^ ((row >> 1) & 7)) << 2)) = ra[c];
+        const int row = id >> 3, slot = id & 7;
+        const int gk = k0 + slot * 4;
+        const bool rok = m0 + row < p.M;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (rok && gk + e < kend) ? v[e] : 0.f;
+        *reinterpret_cast<f32x4*>(a + row * BK + ((slot ^ ((row >> 1) & 7)) << 2)) = v;
       } else {
-        *reinterpret_cast<f32x4*>(a + id * 4) = ra[c];  // [kk][BM] is exactly chunk order
+        const int gk = k0 + id / (BM / 4), gm = m0 + (id % (BM / 4)) * 4;
+        if (!(gk < kend && gm < p.M)) v = f32x4{0.f, 0.f, 0.f, 0.f};
+        *reinterpret_cast<f32x4*>(a + id * 4) = v;  // [kk][BM] is exactly chunk order
       }
     }
 #pragma unroll
     for (int c = 0; c < B_CHUNKS; ++c) {
-      int id = tid + c * 256;
+      const int id = tid + c * 256;
+      f32x4 v = rb[c];
       if (B_KMAJOR) {
-        int row = id >> 3, slot = id & 7;
-        *reinterpret_cast<f32x4*>(b + row * BK + ((slot ^ ((row >> 1) & 7)) << 2)) = rb[c];
+        const int row = id >> 3, slot = id & 7;
+        const int gk = k0 + slot * 4;
+        const bool rok = n0 + row < p.N;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (rok && gk + e < kend) ? v[e] : 0.f;
+        *reinterpret_cast<f32x4*>(b + row * BK + ((slot ^ ((row >> 1) & 7)) << 2)) = v;
       } else {
-        *reinterpret_cast<f32x4*>(b + id * 4) = rb[c];
+        const int gk = k0 + id / (BN / 4), gn = n0 + (id % (BN / 4)) * 4;
+        if (!(gk < kend && gn < p.N)) v = f32x4{0.f, 0.f, 0.f, 0.f};
+        *reinterpret_cast<f32x4*>(b + id * 4) = v;
       }
     }
   };
 
+  auto read_frags = [&](const float* a, const float* b, int g, f32x4 (&fa)[MT], f32x4 (&fb)[NT]) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int row = wm * TM + i * 32 + l31;
+      if (A_KMAJOR) {
+        fa[i] = *reinterpret_cast<const f32x4*>(a + row * BK + (((2 * g + half) ^ ((row >> 1) & 7)) << 2));
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) fa[i][r] = a[(8 * g + 4 * half + r) * BM + row];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int row = wn * TN + j * 32 + l31;
+      if (B_KMAJOR) {
+        fb[j] = *reinterpret_cast<const f32x4*>(b + row * BK + (((2 * g + half) ^ ((row >> 1) & 7)) << 2));
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) fb[j][r] = b[(8 * g + 4 * half + r) * BN + row];
+      }
+    }
+  };
+
+  // fragments of k-group g+1 are read from LDS before the 4*MT*NT MFMAs of group g are issued
   auto compute_tile = [&](int buf) {
     const float* a = As + buf * BM * BK;
     const float* b = Bs + buf * BN * BK;
+    f32x4 fa[2][MT], fb[2][NT];
+    read_frags(a, b, 0, fa[0], fb[0]);
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      f32x4 fa[MT], fb[NT];
-#pragma unroll
-      for (int i = 0; i < MT; ++i) {
-        int row = wm * TM + i * 32 + l31;
-        if (A_KMAJOR) {
-          fa[i] = *reinterpret_cast<const f32x4*>(a + row * BK + (((2 * g + half) ^ ((row >> 1) & 7)) << 2));
-        } else {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) fa[i][r] = a[(8 * g + 4 * half + r) * BM + row];
-        }
-      }
-#pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        int row = wn * TN + j * 32 + l31;
-        if (B_KMAJOR) {
-          fb[j] = *reinterpret_cast<const f32x4*>(b + row * BK + (((2 * g + half) ^ ((row >> 1) & 7)) << 2));
-        } else {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) fb[j][r] = b[(8 * g + 4 * half + r) * BN + row];
-        }
-      }
+      if (g + 1 < 4) read_frags(a, b, g + 1, fa[(g + 1) & 1], fb[(g + 1) & 1]);
 #pragma unroll
       for (int r = 0; r < 4; ++r)
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
           for (int j = 0; j < NT; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][r], fb[j][r], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[g & 1][i][r], fb[g & 1][j][r], acc[i][j], 0, 0, 0);
     }
   };
 
   if (nk > 0) {
     load_tile(0);
-    store_tile(0);
+    store_tile(0, 0);
   }
   __syncthreads();
   for (int kt = 0; kt < nk; ++kt) {
     const int buf = kt & 1;
     if (kt + 1 < nk) load_tile(kt + 1);
     compute_tile(buf);
-    if (kt + 1 < nk) store_tile(buf ^ 1);
+    if (kt + 1 < nk) store_tile(buf ^ 1, kt + 1);
     __syncthreads();
   }
 
@@ -270,20 +279,46 @@ __global__ void __launch_bounds__(256, 2) gemm_f32_kernel(GemmParams p) {
       }
     return;
   }
-  // epilogue: acc register r of tile (i,j) is C[row = (r&3) + 8*(r>>2) + 4*half][col = lane&31]
+  // epilogue: acc register r of tile (i,j) is C[row = (r&3) + 8*(r>>2) + 4*half][col = lane&31].
+  // All side inputs of a 32x32 tile (residual / aux / old C) are loaded back to back from clamped addresses before
+  // any of them is used, so their latency is paid once per tile instead of once per element.
+  const int epi = p.slab ? 0 : p.epilogue;
 #pragma unroll
   for (int i = 0; i < MT; ++i)
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
       const int col = n0 + wn * TN + j * 32 + l31;
+      const int colc = min(col, p.N - 1);
+      const int rbase = m0 + wm * TM + i * 32 + 4 * half;
+      const float bcol = (epi & DCLIP_EPI_BIAS) ? p.bias[colc] : 0.f;
+      float side0[16], side1[16];
+      if (epi & (DCLIP_EPI_RESIDUAL | DCLIP_EPI_DGELU | DCLIP_EPI_ACCUM)) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const size_t off = (size_t)min(rbase + (r & 3) + 8 * (r >> 2), p.M - 1) * p.ldc + colc;
+          side0[r] = (epi & DCLIP_EPI_DGELU) ? p.aux[off] : ((epi & DCLIP_EPI_RESIDUAL) ? p.residual[off] : 0.f);
+          side1[r] = (epi & DCLIP_EPI_ACCUM) ? p.C[off] : 0.f;
+        }
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        const int row = rbase + (r & 3) + 8 * (r >> 2);
         if (row < p.M && col < p.N) {
+          float v = acc[i][j][r];
           if (p.slab) {
-            p.slab[((size_t)blockIdx.y * p.M + row) * p.N + col] = acc[i][j][r];
+            p.slab[((size_t)blockIdx.y * p.M + row) * p.N + col] = v;
           } else {
-            apply_epilogue_store(p, row, col, acc[i][j][r]);
+            const size_t off = (size_t)row * p.ldc + col;
+            v = v * p.alpha + bcol;
+            if (epi & DCLIP_EPI_GELU) {
+              if (p.aux) p.aux[off] = v;
+              v = quick_gelu_f(v);
+            }
+            if (epi & DCLIP_EPI_DGELU) v *= quick_gelu_grad_f(side0[r]);
+            else if (epi & DCLIP_EPI_RESIDUAL) v += side0[r];
+            if ((epi & DCLIP_EPI_DGELU) && (epi & DCLIP_EPI_RESIDUAL)) v += p.residual[off];
+            v += side1[r];
+            p.C[off] = v;
           }
         }
       }
@@ -329,6 +364,14 @@ struct Plan {
 // compute-bound, so the choice is about filling 256 CUs x 2 resident workgroups with few idle tails.
 Plan make_plan(int M, int N, int K, int split_k) {
   const int cand[4][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}};
+  if (const char* force = getenv("DCLIP_GEMM_TILE")) {  // tuning aid: "BMxBN[xSPLITS]"
+    int bm = 0, bn = 0, sp = 1;
+    if (sscanf(force, "%dx%dx%d", &bm, &bn, &sp) >= 2 && (bm == 64 || bm == 128) && (bn == 64 || bn == 128)) {
+      if (split_k > 0) sp = split_k;
+      int kps = cdiv(cdiv(K, sp), BK) * BK;
+      return Plan{bm, bn, cdiv(K, kps), kps};
+    }
+  }
   double best = 1e300;
   Plan pl{128, 128, 1, K};
   for (auto& c : cand) {
