@@ -104,55 +104,66 @@ __global__ void __launch_bounds__(256, 2) gemm_f32_kernel(GemmParams p) {
 
   f32x4 ra[A_CHUNKS], rb[B_CHUNKS];
 
-  // Branch-free staging: every lane always issues its 16-byte load from an address clamped into the operand
-  // (load_tile), and out-of-range elements are zeroed with selects only when the registers are written to LDS
-  // (store_tile), AFTER the MFMA block — so the loads' latency hides under the current tile's MFMAs.  (A per-load
-  // branch makes hipcc wrap each load in exec-mask control flow; a select right after the load makes it wait there.)
-  const int k_last4 = (p.K - 1) & ~3;  // start of the last (possibly partial) 4-chunk of a K-major row
+  // ---- staging through buffer loads -------------------------------------------------------------------------
+  // Each operand gets one buffer descriptor (SRD) whose base is this workgroup's tile origin; every staged
+  // 16-byte chunk has a per-lane byte offset computed ONCE, and walking K only changes the scalar offset — no
+  // vector ALU work per K-tile.  Rows past M/N are clamped onto the last valid row (they only feed output rows /
+  // columns that are never stored).  For an [K][M]-major operand rows past kend fall outside the descriptor and
+  // read as zero; for a K-major operand a ragged K tail (K % 32 != 0) is zeroed with selects in the last tile only.
+  const float* a_org = A_KMAJOR ? p.A + (size_t)m0 * p.lda + kbeg : p.A + (size_t)kbeg * p.lda + m0;
+  const float* b_org = B_KMAJOR ? p.B + (size_t)n0 * p.ldb + kbeg : p.B + (size_t)kbeg * p.ldb + n0;
+  const int a_rows = min(BM, p.M - m0), b_rows = min(BN, p.N - n0);
+  const int kspan = kend - kbeg;  // > 0
+  const size_t a_bytes = A_KMAJOR ? ((size_t)(a_rows - 1) * p.lda + (p.K - kbeg)) * 4
+                                  : ((size_t)(kspan - 1) * p.lda + (p.M - m0)) * 4;
+  const size_t b_bytes = B_KMAJOR ? ((size_t)(b_rows - 1) * p.ldb + (p.K - kbeg)) * 4
+                                  : ((size_t)(kspan - 1) * p.ldb + (p.N - n0)) * 4;
+  const __amdgpu_buffer_rsrc_t a_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a_org), 0, (int)min(a_bytes, (size_t)0x7fffffff), 0x00020000);
+  const __amdgpu_buffer_rsrc_t b_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(b_org), 0, (int)min(b_bytes, (size_t)0x7fffffff), 0x00020000);
+  const int a_kstep = A_KMAJOR ? BK * 4 : BK * p.lda * 4;  // scalar byte advance per K-tile
+  const int b_kstep = B_KMAJOR ? BK * 4 : BK * p.ldb * 4;
+  int a_voff[A_CHUNKS], b_voff[B_CHUNKS];
+#pragma unroll
+  for (int c = 0; c < A_CHUNKS; ++c) {
+    const int id = tid + c * 256;
+    if (A_KMAJOR) a_voff[c] = (min(id >> 3, a_rows - 1) * p.lda + (id & 7) * 4) * 4;
+    else a_voff[c] = ((id / (BM / 4)) * p.lda + min((id % (BM / 4)) * 4, p.M - m0 - 4)) * 4;
+  }
+#pragma unroll
+  for (int c = 0; c < B_CHUNKS; ++c) {
+    const int id = tid + c * 256;
+    if (B_KMAJOR) b_voff[c] = (min(id >> 3, b_rows - 1) * p.ldb + (id & 7) * 4) * 4;
+    else b_voff[c] = ((id / (BN / 4)) * p.ldb + min((id % (BN / 4)) * 4, p.N - n0 - 4)) * 4;
+  }
+
   auto load_tile = [&](int kt) {
-    const int k0 = kbeg + kt * BK;
 #pragma unroll
-    for (int c = 0; c < A_CHUNKS; ++c) {
-      const int id = tid + c * 256;
-      if (A_KMAJOR) {  // rows of 8 chunks
-        const int gm = m0 + (id >> 3), gk = k0 + (id & 7) * 4;
-        ra[c] = *reinterpret_cast<const f32x4*>(p.A + (size_t)min(gm, p.M - 1) * p.lda + min(gk, k_last4));
-      } else {  // [32][BM]: BM/4 chunks per k row
-        const int gk = k0 + id / (BM / 4), gm = m0 + (id % (BM / 4)) * 4;
-        ra[c] = *reinterpret_cast<const f32x4*>(p.A + (size_t)min(gk, p.K - 1) * p.lda + min(gm, p.M - 4));
-      }
-    }
+    for (int c = 0; c < A_CHUNKS; ++c)
+      ra[c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, a_voff[c], kt * a_kstep, 0));
 #pragma unroll
-    for (int c = 0; c < B_CHUNKS; ++c) {
-      const int id = tid + c * 256;
-      if (B_KMAJOR) {
-        const int gn = n0 + (id >> 3), gk = k0 + (id & 7) * 4;
-        rb[c] = *reinterpret_cast<const f32x4*>(p.B + (size_t)min(gn, p.N - 1) * p.ldb + min(gk, k_last4));
-      } else {
-        const int gk = k0 + id / (BN / 4), gn = n0 + (id % (BN / 4)) * 4;
-        rb[c] = *reinterpret_cast<const f32x4*>(p.B + (size_t)min(gk, p.K - 1) * p.ldb + min(gn, p.N - 4));
-      }
-    }
+    for (int c = 0; c < B_CHUNKS; ++c)
+      rb[c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, b_voff[c], kt * b_kstep, 0));
   };
 
-  auto store_tile = [&](int buf, int kt) {
-    const int k0 = kbeg + kt * BK;
+  // registers -> LDS.  `ragged`: this is the last, partial K-tile of a K-major operand: zero k >= kend.
+  auto store_tile = [&](int buf, int kt, bool ragged) {
     float* a = As + buf * BM * BK;
     float* b = Bs + buf * BN * BK;
+    const int krem = kspan - kt * BK;  // valid k in this tile (>= BK unless ragged)
 #pragma unroll
     for (int c = 0; c < A_CHUNKS; ++c) {
       const int id = tid + c * 256;
       f32x4 v = ra[c];
       if (A_KMAJOR) {
         const int row = id >> 3, slot = id & 7;
-        const int gk = k0 + slot * 4;
-        const bool rok = m0 + row < p.M;
+        if (ragged) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = (rok && gk + e < kend) ? v[e] : 0.f;
+          for (int e = 0; e < 4; ++e) v[e] = (slot * 4 + e < krem) ? v[e] : 0.f;
+        }
         *reinterpret_cast<f32x4*>(a + row * BK + ((slot ^ ((row >> 1) & 7)) << 2)) = v;
       } else {
-        const int gk = k0 + id / (BM / 4), gm = m0 + (id % (BM / 4)) * 4;
-        if (!(gk < kend && gm < p.M)) v = f32x4{0.f, 0.f, 0.f, 0.f};
         *reinterpret_cast<f32x4*>(a + id * 4) = v;  // [kk][BM] is exactly chunk order
       }
     }
@@ -162,14 +173,12 @@ __global__ void __launch_bounds__(256, 2) gemm_f32_kernel(GemmParams p) {
       f32x4 v = rb[c];
       if (B_KMAJOR) {
         const int row = id >> 3, slot = id & 7;
-        const int gk = k0 + slot * 4;
-        const bool rok = n0 + row < p.N;
+        if (ragged) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = (rok && gk + e < kend) ? v[e] : 0.f;
+          for (int e = 0; e < 4; ++e) v[e] = (slot * 4 + e < krem) ? v[e] : 0.f;
+        }
         *reinterpret_cast<f32x4*>(b + row * BK + ((slot ^ ((row >> 1) & 7)) << 2)) = v;
       } else {
-        const int gk = k0 + id / (BN / 4), gn = n0 + (id % (BN / 4)) * 4;
-        if (!(gk < kend && gn < p.N)) v = f32x4{0.f, 0.f, 0.f, 0.f};
         *reinterpret_cast<f32x4*>(b + id * 4) = v;
       }
     }
@@ -217,16 +226,19 @@ __global__ void __launch_bounds__(256, 2) gemm_f32_kernel(GemmParams p) {
     }
   };
 
-  if (nk > 0) {
-    load_tile(0);
-    store_tile(0, 0);
-  }
+  const bool k_ragged = (A_KMAJOR || B_KMAJOR) && (kspan % BK) != 0;  // only the last tile can be partial
+  load_tile(0);
+  if (k_ragged && nk == 1) store_tile(0, 0, true);
+  else store_tile(0, 0, false);
   __syncthreads();
   for (int kt = 0; kt < nk; ++kt) {
     const int buf = kt & 1;
     if (kt + 1 < nk) load_tile(kt + 1);
     compute_tile(buf);
-    if (kt + 1 < nk) store_tile(buf ^ 1, kt + 1);
+    if (kt + 1 < nk) {
+      if (k_ragged && kt + 2 == nk) store_tile(buf ^ 1, kt + 1, true);
+      else store_tile(buf ^ 1, kt + 1, false);
+    }
     __syncthreads();
   }
 
@@ -283,23 +295,36 @@ __global__ void __launch_bounds__(256, 2) gemm_f32_kernel(GemmParams p) {
   // All side inputs of a 32x32 tile (residual / aux / old C) are loaded back to back from clamped addresses before
   // any of them is used, so their latency is paid once per tile instead of once per element.
   const int epi = p.slab ? 0 : p.epilogue;
+  const bool has_side0 = epi & (DCLIP_EPI_RESIDUAL | DCLIP_EPI_DGELU);
+  const bool has_side1 = epi & DCLIP_EPI_ACCUM;
+  float side0[MT][NT][16], side1[MT][NT][16], bcol[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int colc = min(n0 + wn * TN + j * 32 + l31, p.N - 1);
+    bcol[j] = (epi & DCLIP_EPI_BIAS) ? p.bias[colc] : 0.f;
+  }
+  if (has_side0 || has_side1) {
+    const float* s0 = (epi & DCLIP_EPI_DGELU) ? p.aux : p.residual;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int colc = min(n0 + wn * TN + j * 32 + l31, p.N - 1);
+        const int rbase = m0 + wm * TM + i * 32 + 4 * half;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const size_t off = (size_t)min(rbase + (r & 3) + 8 * (r >> 2), p.M - 1) * p.ldc + colc;
+          side0[i][j][r] = has_side0 ? s0[off] : 0.f;
+          side1[i][j][r] = has_side1 ? p.C[off] : 0.f;
+        }
+      }
+  }
 #pragma unroll
   for (int i = 0; i < MT; ++i)
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
       const int col = n0 + wn * TN + j * 32 + l31;
-      const int colc = min(col, p.N - 1);
       const int rbase = m0 + wm * TM + i * 32 + 4 * half;
-      const float bcol = (epi & DCLIP_EPI_BIAS) ? p.bias[colc] : 0.f;
-      float side0[16], side1[16];
-      if (epi & (DCLIP_EPI_RESIDUAL | DCLIP_EPI_DGELU | DCLIP_EPI_ACCUM)) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const size_t off = (size_t)min(rbase + (r & 3) + 8 * (r >> 2), p.M - 1) * p.ldc + colc;
-          side0[r] = (epi & DCLIP_EPI_DGELU) ? p.aux[off] : ((epi & DCLIP_EPI_RESIDUAL) ? p.residual[off] : 0.f);
-          side1[r] = (epi & DCLIP_EPI_ACCUM) ? p.C[off] : 0.f;
-        }
-      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = rbase + (r & 3) + 8 * (r >> 2);
@@ -309,15 +334,18 @@ __global__ void __launch_bounds__(256, 2) gemm_f32_kernel(GemmParams p) {
             p.slab[((size_t)blockIdx.y * p.M + row) * p.N + col] = v;
           } else {
             const size_t off = (size_t)row * p.ldc + col;
-            v = v * p.alpha + bcol;
+            v = v * p.alpha + bcol[j];
             if (epi & DCLIP_EPI_GELU) {
               if (p.aux) p.aux[off] = v;
               v = quick_gelu_f(v);
             }
-            if (epi & DCLIP_EPI_DGELU) v *= quick_gelu_grad_f(side0[r]);
-            else if (epi & DCLIP_EPI_RESIDUAL) v += side0[r];
-            if ((epi & DCLIP_EPI_DGELU) && (epi & DCLIP_EPI_RESIDUAL)) v += p.residual[off];
-            v += side1[r];
+            if (epi & DCLIP_EPI_DGELU) {
+              v *= quick_gelu_grad_f(side0[i][j][r]);
+              if (epi & DCLIP_EPI_RESIDUAL) v += p.residual[off];
+            } else if (epi & DCLIP_EPI_RESIDUAL) {
+              v += side0[i][j][r];
+            }
+            if (has_side1) v += side1[i][j][r];
             p.C[off] = v;
           }
         }
