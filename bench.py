@@ -140,10 +140,14 @@ def main():
             raise SystemExit(f"--gpus {args.gpus} needs one process per GPU: launch with "
                              f"python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py ...")
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback)"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    backend = os.environ.get("DCLIP_DIST_BACKEND", "nccl")     # "gloo" lets N ranks share one GPU for a rehearsal
+    if world > 1 and backend == "nccl" and ndev < world:
+        raise SystemExit(f"{world} ranks need {world} GPUs (found {ndev})")
+    torch.cuda.set_device(local_rank % ndev)
+    dev = torch.device("cuda", local_rank % ndev)
     from dclip_amd import dist as ddist
-    group = ddist.init_from_env("nccl") if world > 1 else None
+    group = ddist.init_from_env(backend) if world > 1 else None
 
     from dclip_amd.clip_model import from_hf_state_dict
     from dclip_amd.CLIP_image_distillation import CLIPImageDistillation

@@ -87,8 +87,15 @@ __global__ void __launch_bounds__(256, 2) gemm_f32_kernel(GemmParams p) {
   const int l31 = lane & 31, half = lane >> 5;
 
   const int nwg = p.tiles_m * p.tiles_n;
+  // Each XCD walks a contiguous range of `swz`; inside it tiles are visited in groups of GROUP_M tile-rows, column
+  // by column, so the ~64 workgroups resident on one XCD cover an ~8x8 patch of tiles: every A / B panel slice
+  // fetched into that XCD's L2 is shared by 8 tiles (fabric reads ~ |A|*tiles_n/8 + |B|*tiles_m/8).
+  constexpr int GROUP_M = 8;
   const int swz = xcd_remap(blockIdx.x, nwg);
-  const int tile_m = swz / p.tiles_n, tile_n = swz % p.tiles_n;
+  const int per_group = GROUP_M * p.tiles_n;
+  const int first_m = (swz / per_group) * GROUP_M;
+  const int gsize = min(GROUP_M, p.tiles_m - first_m);
+  const int tile_m = first_m + (swz % per_group) % gsize, tile_n = (swz % per_group) / gsize;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int kbeg = blockIdx.y * p.k_per_split;
   const int kend = min(p.K, kbeg + p.k_per_split);

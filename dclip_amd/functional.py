@@ -39,7 +39,6 @@ class TextTowerFn(torch.autograd.Function):
         save = any(ctx.needs_input_grad[3:])
         out, saved = engine.text_fwd(p, _c(input_ids), cfg, save)
         ctx.p, ctx.saved, ctx.cfg = p, saved, cfg
-        ctx.mark_non_differentiable()
         return out
 
     @staticmethod
@@ -92,8 +91,9 @@ class ContrastiveLossFn(torch.autograd.Function):
             import torch.distributed as dist
             world, rank = dist.get_world_size(group), dist.get_rank(group)
             both = torch.stack([ihat, that])                               # [2, Bl, P]: one collective for both
-            gathered = torch.empty((world,) + tuple(both.shape), dtype=both.dtype, device=both.device)
-            dist.all_gather_into_tensor(gathered, both, group=group)
+            gathered = torch.empty((world * 2,) + tuple(both.shape[1:]), dtype=both.dtype, device=both.device)
+            dist.all_gather_into_tensor(gathered, both, group=group)      # rank-major concatenation along dim 0
+            gathered = gathered.view((world, 2) + tuple(both.shape[1:]))
             i_all = gathered[:, 0].reshape(world * Bl, -1).contiguous()
             t_all = gathered[:, 1].reshape(world * Bl, -1).contiguous()
         else:
@@ -104,8 +104,9 @@ class ContrastiveLossFn(torch.autograd.Function):
         lse_t, _ = ops.contrastive_lse(that, i_all, off, inv_t)          # text rows vs all images
         if group is not None:
             both = torch.stack([lse_i, lse_t])
-            g2 = torch.empty((world,) + tuple(both.shape), dtype=both.dtype, device=both.device)
+            g2 = torch.empty((world * 2, Bl), dtype=both.dtype, device=both.device)
             dist.all_gather_into_tensor(g2, both, group=group)
+            g2 = g2.view(world, 2, Bl)
             lse_i_all = g2[:, 0].reshape(-1).contiguous()
             lse_t_all = g2[:, 1].reshape(-1).contiguous()
         else:

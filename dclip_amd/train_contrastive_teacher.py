@@ -1,0 +1,188 @@
+"""`train_contrastive_teacher.main(args)` — the teacher trainer entry point, same arguments and the same checkpoint
+files as training/train_contrastive_teacher.py, with the step on the HIP kernels.
+
+What is kept (training/train_contrastive_teacher.py):
+  * seed 42 (:99); everything frozen except parameters whose name contains cross_attn|attention|proj|fusion|final
+    (:126-134) — on the teacher that is exactly the 12 tensors of `cross_modal_attention.*`;
+  * Adam(lr=args.learning_rate) over the trainable set (:245-248); `--gradient_accumulation` is parsed and, as in
+    the reference, not used (:435);
+  * per batch: meta-teacher image embedding vs CLIP sentence embedding under the symmetric InfoNCE with
+    temperature 0.05 (:251-261, :340-362);
+  * `torch.save(teacher.state_dict(), f"{stem}_epoch{N}_val{loss:.4f}.pth")` every epoch, best → `output_path`,
+    `output_path + ".interrupt.pth"` / `".error.pth"` on Ctrl-C / exception (:394-420).
+
+What differs: models are never fetched by name — `args.clip_path` names a LOCAL directory with HF CLIP weights (or
+`teacher=` is passed in); batches may be the reference's `(images, captions, paths, boxes)` tuples (needs a
+tokenizer) or tensor dicts `{regions, input_ids[, region_counts]}`; the DBM KNN cache (:19-95) feeds only the
+out-of-scope KNN tokenizer and is not built.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import random
+from typing import Iterable, Optional
+
+import numpy as np
+import torch
+
+from . import functional
+from .patch_text_aggregation import PatchTextAggregation
+
+
+def seed_everything(seed: int = 42):
+    random.seed(seed)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    if torch.cuda.is_available():
+        torch.cuda.manual_seed_all(seed)
+
+
+def compute_contrastive_loss(image_embeddings, text_embeddings, temperature=0.05, group=None):
+    """:251-261 (textually the same function as CLIP_image_distillation.py:532-562)."""
+    return functional.contrastive_loss(image_embeddings, text_embeddings, temperature, group)
+
+
+class JsonPairDataset:
+    """`[{image_path, captions|caption, boxes?}]` (json_creation/big_teacher_data.py:86-91) → the reference's batch
+    tuples; boxes come from the JSON (or an empty list): there is no detector here."""
+
+    def __init__(self, json_file: str, batch_size: int, shuffle: bool, seed: int = 42):
+        with open(json_file, "r", encoding="utf-8") as f:
+            self.data = json.load(f)
+        self.batch_size, self.shuffle = batch_size, shuffle
+        self.rng = random.Random(seed)
+
+    def __len__(self):
+        return (len(self.data) + self.batch_size - 1) // self.batch_size
+
+    def __iter__(self):
+        order = list(range(len(self.data)))
+        if self.shuffle:
+            self.rng.shuffle(order)
+        for i in range(0, len(order), self.batch_size):
+            items = [self.data[j] for j in order[i:i + self.batch_size]]
+            caps = []
+            for it in items:
+                c = it.get("captions", it.get("caption", ""))
+                caps.append(c[0] if isinstance(c, list) and c else (c if isinstance(c, str) else ""))
+            paths = [it.get("image_path", "") for it in items]
+            boxes = [[(tuple(b[0]), float(b[1])) if isinstance(b[0], (list, tuple)) else (tuple(b[:4]), 1.0)
+                      for b in it.get("boxes", [])] for it in items]
+            yield None, caps, paths, boxes
+
+
+def _embeddings(teacher: PatchTextAggregation, batch):
+    if isinstance(batch, dict):
+        dev = teacher.device
+        ids = batch["input_ids"].to(dev)
+        img = teacher.compute_global_embedding_tensors(batch["regions"].to(dev), ids, batch.get("region_counts"),
+                                                       batch.get("max_tokens"))
+        txt = teacher.text_tokenizer.aggregate_text_ids(ids)
+    else:
+        _, captions, image_paths, weighted_boxes_batch = batch
+        img = teacher.compute_global_embedding_batch(image_paths, captions, weighted_boxes_batch)
+        txt = torch.stack([teacher.text_tokenizer.aggregate_text(c) for c in captions])
+    return img, txt
+
+
+def build_teacher(args, device) -> PatchTextAggregation:
+    from .clip_model import from_hf_state_dict
+    from .config import from_hf
+    path = getattr(args, "clip_path", None)
+    if not path or not os.path.isdir(path):
+        raise SystemExit("--clip_path must name a local directory with HF CLIP weights (nothing is downloaded by name)")
+    from transformers import CLIPModel, CLIPTokenizer
+    hf = CLIPModel.from_pretrained(path, local_files_only=True)
+    clip = from_hf_state_dict(from_hf(hf.config), hf.state_dict(), device=device)
+    tok = CLIPTokenizer.from_pretrained(path, local_files_only=True)
+    return PatchTextAggregation(embed_dim=clip.config.projection_dim, num_heads=clip.config.projection_dim // 64,
+                                similarity_threshold=0.85, projection_model_path="", faiss_index_path="",
+                                embeddings_json_path="", clip_model=clip, tokenizer=tok).to(device)
+
+
+def main(args, teacher: Optional[PatchTextAggregation] = None, train_batches: Optional[Iterable] = None,
+         val_batches: Optional[Iterable] = None):
+    seed_everything(42)
+    device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
+    if teacher is None:
+        teacher = build_teacher(args, device)
+
+    for param in teacher.parameters():
+        param.requires_grad = False
+    for name, param in teacher.named_parameters():
+        if any(key in name for key in ["cross_attn", "attention", "proj", "fusion", "final"]):
+            param.requires_grad = True
+    trainable = [p for p in teacher.parameters() if p.requires_grad]
+    print(f"Training {sum(p.numel() for p in trainable):,} parameters out of "
+          f"{sum(p.numel() for p in teacher.parameters()):,}")
+
+    if train_batches is None:
+        train_batches = JsonPairDataset(args.train_file, args.batch_size, shuffle=True)
+    if val_batches is None and getattr(args, "val_file", None) and os.path.exists(args.val_file):
+        val_batches = JsonPairDataset(args.val_file, args.batch_size, shuffle=False)
+
+    optimizer = torch.optim.Adam(trainable, lr=args.learning_rate)
+
+    def validate():
+        teacher.eval()
+        total, n = 0.0, 0
+        with torch.no_grad():
+            for batch in (val_batches or []):
+                img, txt = _embeddings(teacher, batch)
+                total += float(compute_contrastive_loss(img, txt))
+                n += 1
+        return {"combined": total / max(1, n)}
+
+    out_dir = os.path.dirname(args.output_path)
+    if out_dir:
+        os.makedirs(out_dir, exist_ok=True)
+    best_val_loss = float("inf")
+    history = []
+    try:
+        for epoch in range(args.epochs):
+            teacher.train()
+            epoch_loss, n = 0.0, 0
+            for batch_idx, batch in enumerate(train_batches):
+                optimizer.zero_grad()
+                img_emb, txt_emb = _embeddings(teacher, batch)
+                loss = compute_contrastive_loss(img_emb, txt_emb)
+                loss.backward()
+                optimizer.step()
+                epoch_loss += float(loss.detach())
+                n += 1
+            avg_loss = epoch_loss / max(1, n)
+            val_losses = validate()
+            history.append((avg_loss, val_losses["combined"]))
+            print(f"Epoch {epoch + 1}/{args.epochs}  train {avg_loss:.4f}  val {val_losses['combined']:.4f}")
+            epoch_save_path = f"{args.output_path.rsplit('.', 1)[0]}_epoch{epoch + 1}_val{val_losses['combined']:.4f}.pth"
+            torch.save(teacher.state_dict(), epoch_save_path)
+            if val_losses["combined"] < best_val_loss:
+                best_val_loss = val_losses["combined"]
+                torch.save(teacher.state_dict(), args.output_path)
+    except KeyboardInterrupt:
+        torch.save(teacher.state_dict(), args.output_path + ".interrupt.pth")
+    except Exception:
+        torch.save(teacher.state_dict(), args.output_path + ".error.pth")
+        raise
+    return {"best_val_loss": best_val_loss, "history": history}
+
+
+def build_parser() -> argparse.ArgumentParser:
+    """:430-441 — same flags and defaults (+ --clip_path, because nothing is fetched by name)."""
+    parser = argparse.ArgumentParser(description="Train Contrastive-Aware Teacher with Gradient Accumulation")
+    parser.add_argument("--train_file", type=str, required=True, help="Path to training JSON file")
+    parser.add_argument("--val_file", type=str, default=None, help="Path to validation JSON file (optional)")
+    parser.add_argument("--batch_size", type=int, default=64, help="Batch size per accumulation step")
+    parser.add_argument("--gradient_accumulation", type=int, default=8, help="Number of gradient accumulation steps")
+    parser.add_argument("--learning_rate", type=float, default=1e-5, help="Learning rate")
+    parser.add_argument("--epochs", type=int, default=5, help="Number of epochs")
+    parser.add_argument("--output_path", type=str, default="./teacher_contrastive/contrastive_teacher_ViT-16.pth",
+                        help="Path to save the trained teacher model")
+    parser.add_argument("--clip_path", type=str, default=None, help="LOCAL directory with HF CLIP weights + tokenizer")
+    return parser
+
+
+if __name__ == "__main__":
+    main(build_parser().parse_args())

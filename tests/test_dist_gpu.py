@@ -1,0 +1,79 @@
+"""Two data-parallel ranks on the ONE GPU of the test box (gloo rendezvous, both ranks on cuda:0): the real kernels,
+the global-negatives exchange and GradSync together reproduce the single-process step on the concatenated batch."""
+import argparse
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from dclip_amd import config as dcfg, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _build(dev, group):
+    from dclip_amd.clip_model import from_hf_state_dict
+    from dclip_amd.CLIP_image_distillation import CLIPImageDistillation
+    from dclip_amd.patch_text_aggregation import PatchTextAggregation
+    cfg = dcfg.tiny()
+    student = from_hf_state_dict(cfg, synth.synth_clip_state_dict(cfg, seed=7, gain=4.0), device=dev)
+    teacher = PatchTextAggregation(embed_dim=cfg.projection_dim, num_heads=1, clip_model=student).to(dev)
+    hp = argparse.Namespace(learning_rate=1e-3, warmup_steps=0, total_steps=10, train_batch_size=4, eval_batch_size=4)
+    return cfg, CLIPImageDistillation(hp, student, None, teacher=teacher, freeze_mode="north_star",
+                                      process_group=group).to(dev)
+
+
+def _batch(cfg, B):
+    return {"pixel_values": synth.synth_pixel_values(B, cfg.vision, seed=0),
+            "input_ids": synth.synth_input_ids(B, cfg.text, seed=3, ragged=True),
+            "teacher_image_emb": synth.synth_embeddings(B, cfg.projection_dim, seed=1),
+            "teacher_text_emb": synth.synth_embeddings(B, cfg.projection_dim, seed=5)}
+
+
+def _worker(rank, world, port, B, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from dclip_amd import dist as ddist
+    dev = torch.device("cuda:0")
+    cfg, mod = _build(dev, dist.group.WORLD)
+    full = _batch(cfg, B)
+    Bl = B // world
+    shard = {k: v[rank * Bl:(rank + 1) * Bl].contiguous() for k, v in full.items()}
+    share = mod.training_step(shard)
+    share.backward()
+    trainable = [p for p in mod.parameters() if p.requires_grad]
+    ddist.GradSync(trainable, dist.group.WORLD, bucket_mb=0.05).reduce()
+    tot = share.detach().clone()
+    dist.all_reduce(tot)
+    torch.cuda.synchronize()
+    out[rank] = dict(loss=float(tot), g_proj=mod.student.visual_projection.weight.grad.cpu(),
+                     g_qkv=mod.student.vision_model.encoder.layers[0].self_attn.qkv_proj.weight.grad.cpu())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_equal_single_process():
+    B, world = 8, 2
+    out = mp.Manager().dict()
+    mp.spawn(_worker, args=(world, _free_port(), B, out), nprocs=world, join=True)
+    dev = torch.device("cuda:0")
+    cfg, mod = _build(dev, None)
+    loss = mod.training_step(_batch(cfg, B))
+    loss.backward()
+    g_proj = mod.student.visual_projection.weight.grad.cpu()
+    g_qkv = mod.student.vision_model.encoder.layers[0].self_attn.qkv_proj.weight.grad.cpu()
+    for r in range(world):
+        assert abs(out[r]["loss"] - float(loss.detach())) < 1e-5 * abs(float(loss.detach()))
+        assert float((out[r]["g_proj"] - g_proj).abs().max()) < 2e-5 * float(g_proj.abs().max())
+        assert float((out[r]["g_qkv"] - g_qkv).abs().max()) < 2e-5 * float(g_qkv.abs().max())
