@@ -52,6 +52,9 @@ SIGNATURES = {
     "dclip_aggregation_bwd": (I, [P, P, P, P, I, I, I, F, F, P]),
     "dclip_pack_tokens": (I, [P, P, P, P, I, I, I, I, P]),
     "dclip_mask_rows": (I, [P, P, I, I, I, P]),
+    "dclip_rank_count_workspace": (Z, [I, I]),
+    "dclip_rowdot_gather": (I, [P, P, P, P, I, I, I, P]),
+    "dclip_rank_count": (I, [P, P, P, P, P, I, I, I, P, Z, P]),
     "dclip_sumsq_blocks": (I, [Z]),
     "dclip_sumsq_f32": (I, [P, Z, P, P]),
     "dclip_clip_coef": (I, [P, I, F, P, P, P]),

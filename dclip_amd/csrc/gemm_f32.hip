@@ -37,15 +37,16 @@ struct GemmParams {
   int k_per_split;  // multiple of BK
   float* slab;      // split-K partials [split][M][N] or nullptr
   // contrastive-loss modes (mode 0 = plain GEMM)
-  int mode;              // 1: row-LSE partials over this tile's columns, 2: dZ tile
+  int mode;              // 1: row-LSE partials over this tile's columns, 2: dZ tile, 3: per-row count of z > lse_row[row]
   const float* lse_row;  // mode 2
   const float* lse_col;  // mode 2
   float* part_m;         // mode 1: [tiles_n*WN][M] running max
   float* part_s;         // mode 1: [tiles_n*WN][M] sum exp(z - max)
   int offset;            // column of row i's positive = i + offset
+  const int32_t* gt;     // mode 3: per-row ground-truth column, excluded from the count (nullptr = row index)
 };
 
-enum { MODE_GEMM = 0, MODE_LSE = 1, MODE_DZ = 2 };
+enum { MODE_GEMM = 0, MODE_LSE = 1, MODE_DZ = 2, MODE_RANK = 3 };
 
 __device__ __forceinline__ void apply_epilogue_store(const GemmParams& p, int row, int col, float v) {
   v *= p.alpha;
@@ -278,6 +279,27 @@ __global__ void __launch_bounds__(256, 2) gemm_f32_kernel(GemmParams p) {
       }
     return;
   }
+  if (p.mode == MODE_RANK) {
+    // count, per row, the columns of this wave's sub-tile whose similarity exceeds the row's threshold
+    const int slot = tile_n * WN + wn;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        const float thr = (row < p.M) ? p.lse_row[row] : 0.f;
+        const int self = (row < p.M) ? (p.gt ? p.gt[row] : row) : -1;
+        float cnt = 0.f;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const int col = n0 + wn * TN + j * 32 + l31;
+          cnt += (col < p.N && col != self && acc[i][j][r] * p.alpha > thr) ? 1.f : 0.f;
+        }
+        cnt = half_sum(cnt);
+        if (l31 == 0 && row < p.M) p.part_s[(size_t)slot * p.M + row] = cnt;
+      }
+    return;
+  }
   if (p.mode == MODE_DZ) {
 #pragma unroll
     for (int i = 0; i < MT; ++i)
@@ -465,7 +487,7 @@ DCLIP_API int dclip_gemm_f32(const float* A, const float* B, float* C, const flo
   Plan pl = make_plan(M, N, K, split_k);
   GemmParams p{A, B, C, bias, residual, aux, M, N, K, lda, ldb, ldc, epilogue, alpha,
                cdiv(M, pl.bm), cdiv(N, pl.bn), pl.k_per_split, nullptr,
-               MODE_GEMM, nullptr, nullptr, nullptr, nullptr, 0};
+               MODE_GEMM, nullptr, nullptr, nullptr, nullptr, 0, nullptr};
   if (pl.splits > 1) {
     const size_t need = (size_t)pl.splits * M * N * sizeof(float);
     if (!workspace || workspace_bytes < need) {
@@ -548,7 +570,7 @@ DCLIP_API int dclip_contrastive_lse(const float* a_local, const float* b_global,
   float* ps = pm + slots * Bl;
   GemmParams p{a_local, b_global, nullptr, nullptr, nullptr, nullptr, Bl, Bg, P, P, P, 0, 0, inv_temp,
                cdiv(Bl, LOSS_BM), cdiv(Bg, LOSS_BN), cdiv(P, BK) * BK, nullptr,
-               MODE_LSE, nullptr, nullptr, pm, ps, offset};
+               MODE_LSE, nullptr, nullptr, pm, ps, offset, nullptr};
   hipStream_t st = (hipStream_t)stream;
   launch_cfg<LOSS_BM, LOSS_BN, 2, LOSS_WN>(p, DCLIP_A_KMAJOR | DCLIP_B_KMAJOR, 1, st);
   DCLIP_CHECK_LAUNCH("contrastive_lse");
@@ -573,10 +595,74 @@ DCLIP_API int dclip_contrastive_grad(const float* a_local, const float* b_global
   // W[i,j] = exp(z_ij - lse_row[i]) + exp(z_ij - lse_col[j]) - 2[j == i+offset]
   GemmParams p{a_local, b_global, W, nullptr, nullptr, nullptr, Bl, Bg, P, P, P, ldw, 0, inv_temp,
                cdiv(Bl, LOSS_BM), cdiv(Bg, LOSS_BN), cdiv(P, BK) * BK, nullptr,
-               MODE_DZ, lse_row, lse_col, nullptr, nullptr, offset};
+               MODE_DZ, lse_row, lse_col, nullptr, nullptr, offset, nullptr};
   launch_cfg<LOSS_BM, LOSS_BN, 2, LOSS_WN>(p, DCLIP_A_KMAJOR | DCLIP_B_KMAJOR, 1, st);
   DCLIP_CHECK_LAUNCH("contrastive_grad.dz");
   // da = coef * W[Bl,Bg] * b_global[Bg,P]   (K = Bg may be ragged; lda = ldw keeps rows 16-byte aligned)
   return dclip_gemm_f32(W, b_global, da_local, nullptr, nullptr, nullptr, Bl, P, Bg, ldw, P, P, DCLIP_A_KMAJOR, 0, coef, 1,
                         nullptr, 0, stream);
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Retrieval / zero-shot ranking on the same similarity tiles (eval_scripts/flickr30k_eval.py:16-88,
+// eval_scripts/test_zero_shot_ImageNet.py:82-103): rank of the ground truth = number of candidates scoring higher.
+namespace {
+
+__global__ void __launch_bounds__(256) rank_merge_kernel(const float* __restrict__ part, int32_t* __restrict__ count, int Bq,
+                                                         int nslots) {
+  const int row = blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= Bq) return;
+  float s = 0.f;
+  for (int k = 0; k < nslots; ++k) s += part[(size_t)k * Bq + row];
+  count[row] = (int32_t)(s + 0.5f);
+}
+
+// out[i] = <a_i, b_{idx[i]}>   (one wave per row)
+__global__ void __launch_bounds__(256) rowdot_gather_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                            const int32_t* __restrict__ idx, float* __restrict__ out, int Bq,
+                                                            int Bk, int P) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= Bq) return;
+  int j = idx ? idx[row] : row;
+  j = j < 0 ? 0 : (j >= Bk ? Bk - 1 : j);
+  float d = 0.f;
+  for (int k = lane; k < P; k += 64) d += a[(size_t)row * P + k] * b[(size_t)j * P + k];
+  d = wave_sum(d);
+  if (lane == 0) out[row] = d;
+}
+
+}  // namespace
+
+DCLIP_API size_t dclip_rank_count_workspace(int Bq, int Bk) { return loss_slots(Bk) * (size_t)Bq * sizeof(float); }
+
+DCLIP_API int dclip_rowdot_gather(const float* a, const float* b, const int32_t* idx, float* out, int Bq, int Bk, int P,
+                                  void* stream) {
+  DCLIP_REQUIRE(a && b && out && Bq > 0 && Bk > 0 && P > 0, "rowdot_gather: bad arguments");
+  hipLaunchKernelGGL(rowdot_gather_kernel, dim3(cdiv(Bq, 4)), dim3(256), 0, (hipStream_t)stream, a, b, idx, out, Bq, Bk, P);
+  DCLIP_CHECK_LAUNCH("rowdot_gather");
+  return DCLIP_OK;
+}
+
+DCLIP_API int dclip_rank_count(const float* queries, const float* candidates, const float* thresh, const int32_t* gt,
+                               int32_t* count, int Bq, int Bk, int P, void* workspace, size_t workspace_bytes,
+                               void* stream) {
+  DCLIP_REQUIRE(queries && candidates && thresh && count, "rank_count: null pointer");
+  DCLIP_REQUIRE(Bq > 0 && Bk > 0 && P > 0 && P % 4 == 0, "rank_count: bad shape Bq=%d Bk=%d P=%d", Bq, Bk, P);
+  const size_t slots = loss_slots(Bk);
+  if (!workspace || workspace_bytes < slots * Bq * sizeof(float)) {
+    dclip_set_error("rank_count: workspace too small");
+    return DCLIP_EWORKSPACE;
+  }
+  float* part = (float*)workspace;
+  GemmParams p{queries, candidates, nullptr, nullptr, nullptr, nullptr, Bq, Bk, P, P, P, 0, 0, 1.0f,
+               cdiv(Bq, LOSS_BM), cdiv(Bk, LOSS_BN), cdiv(P, BK) * BK, nullptr,
+               MODE_RANK, thresh, nullptr, nullptr, part, 0, gt};
+  hipStream_t st = (hipStream_t)stream;
+  launch_cfg<LOSS_BM, LOSS_BN, 2, LOSS_WN>(p, DCLIP_A_KMAJOR | DCLIP_B_KMAJOR, 1, st);
+  DCLIP_CHECK_LAUNCH("rank_count");
+  hipLaunchKernelGGL(rank_merge_kernel, dim3(cdiv(Bq, 256)), dim3(256), 0, st, (const float*)part, count, Bq, (int)slots);
+  DCLIP_CHECK_LAUNCH("rank_count.merge");
+  return DCLIP_OK;
 }

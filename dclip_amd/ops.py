@@ -477,6 +477,43 @@ def mask_rows(x, count):
     return x
 
 
+# ------------------------------------------------------------------------------------------- evaluation
+
+def rowdot_gather(a, b, idx=None):
+    lib = _lib.load()
+    _f32(a, "a"), _f32(b, "b")
+    Bq, Pd = a.shape
+    Bk = b.shape[0]
+    if b.shape[1] != Pd:
+        raise ValueError("rowdot_gather: width mismatch")
+    if idx is not None:
+        _idx(idx, Bq)
+    elif Bk < Bq:
+        raise ValueError("rowdot_gather: idx=None needs Bk >= Bq")
+    out = torch.empty((Bq,), dtype=torch.float32, device=a.device)
+    _lib.check(lib.dclip_rowdot_gather(a.data_ptr(), b.data_ptr(), _ptr(idx), out.data_ptr(), Bq, Bk, Pd, _stream()),
+               "rowdot_gather")
+    return out
+
+
+def rank_count(queries, candidates, thresh, gt=None):
+    """count[i] = #{j != gt[i] : <queries_i, candidates_j> > thresh[i]}  (int32; gt=None means j != i)."""
+    lib = _lib.load()
+    _f32(queries, "queries"), _f32(candidates, "candidates"), _f32(thresh, "thresh")
+    Bq, Pd = queries.shape
+    Bk = candidates.shape[0]
+    if candidates.shape[1] != Pd or thresh.numel() != Bq:
+        raise ValueError("rank_count: shape mismatch")
+    if gt is not None:
+        _idx(gt, Bq)
+    count = torch.empty((Bq,), dtype=torch.int32, device=queries.device)
+    nbytes = lib.dclip_rank_count_workspace(Bq, Bk)
+    ws = _ws.get(nbytes, queries.device)
+    _lib.check(lib.dclip_rank_count(queries.data_ptr(), candidates.data_ptr(), thresh.data_ptr(), _ptr(gt),
+                                    count.data_ptr(), Bq, Bk, Pd, _ptr(ws), nbytes, _stream()), "rank_count")
+    return count
+
+
 def axpby(x, y, a: float, b: float):
     """y = a*x + b*y (in place on y)."""
     lib = _lib.load()

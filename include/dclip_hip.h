@@ -203,6 +203,24 @@ int dclip_pack_tokens(const float* tokens, const float* sentence, const int32_t*
 int dclip_mask_rows(float* x, const int32_t* count, int B, int R, int E, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Checkpoint consumers: retrieval and zero-shot evaluation on the similarity kernel.
+ * The reference materialises caption x image similarities chunk by chunk and argsorts every row / column
+ * (eval_scripts/flickr30k_eval.py:16-88, :249-266; eval_scripts/test_zero_shot_ImageNet.py:82-103).  The rank of a
+ * ground truth is the number of candidates that score strictly higher, so it is computed without the matrix:
+ *   rowdot_gather: out[i] = <a_i, b_{idx[i]}>            (the ground truth's own score; idx NULL = i)
+ *   rank_count:    count[i] = #{ j < Bk, j != gt[i] : <q_i, c_j> > thresh[i] }   (MFMA tiles, per-row counts in the
+ *                  epilogue; gt NULL = i.  The ground truth itself is excluded so that rounding differences between
+ *                  its two evaluations cannot count it as "higher than itself".)
+ * Inputs are L2-normalised rows (dclip_normalize_rows_fwd).  Exact ties count as not-higher (argsort's order
+ * among equal scores is unspecified in the reference).
+ */
+size_t dclip_rank_count_workspace(int Bq, int Bk);
+int dclip_rowdot_gather(const float* a, const float* b, const int32_t* idx, float* out, int Bq, int Bk, int P,
+                        void* stream);
+int dclip_rank_count(const float* queries, const float* candidates, const float* thresh, const int32_t* gt,
+                     int32_t* count, int Bq, int Bk, int P, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Optimiser tail (pulled into the timed step).
  * sumsq / clip_coef: global-norm clipping as torch.nn.utils.clip_grad_norm_ does it, which is what Lightning's
  *   Trainer(gradient_clip_val=0.5) applies (training/CLIP_image_distill_training.py:41): each tensor writes

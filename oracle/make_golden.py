@@ -407,6 +407,30 @@ def gen_step_c1(ref_con, ref_cos):
     save("step_c1.npz", **arrs)
 
 
+# ----------------------------------------------------------------------------- eval consumers
+
+def gen_eval():
+    """`calculate_retrieval_metrics` lifted from eval_scripts/flickr30k_eval.py:16-88 and run on seeded embeddings."""
+    from collections import defaultdict
+    src = open(os.path.join(REF, "eval_scripts", "flickr30k_eval.py")).read()
+    fn = [n for n in ast.parse(src).body if isinstance(n, ast.FunctionDef) and n.name == "calculate_retrieval_metrics"][0]
+    ns = {"np": np, "defaultdict": defaultdict, "print": lambda *a, **k: None}
+    exec(compile(ast.Module(body=[fn], type_ignores=[]), "<lifted>", "exec"), ns)
+    g = torch.Generator().manual_seed(77)
+    Ni, per, Pd = 60, 5, 64
+    img = torch.randn(Ni, Pd, generator=g)
+    cap = img.repeat_interleave(per, 0) * 0.55 + torch.randn(Ni * per, Pd, generator=g)
+    image_ids = [f"img{i}" for i in range(Ni)]
+    caption_image_ids = [f"img{i}" for i in range(Ni) for _ in range(per)]
+    i_n = img.numpy() / np.linalg.norm(img.numpy(), axis=1, keepdims=True)          # :240-246
+    c_n = cap.numpy() / np.linalg.norm(cap.numpy(), axis=1, keepdims=True)
+    m = ns["calculate_retrieval_metrics"](np.matmul(c_n, i_n.T), image_ids, caption_image_ids)
+    arrs = {"image_emb": img, "caption_emb": cap, "per": np.array(per)}
+    for d in ("t2i", "i2t"):
+        arrs[d] = np.array([m[d]["R@1"], m[d]["R@5"], m[d]["R@10"], m[d]["MAP"]])
+    save("eval_retrieval.npz", **arrs)
+
+
 def main():
     which = set(sys.argv[1:])
     pta, tt, it = import_reference_teacher()
@@ -423,6 +447,8 @@ def main():
         gen_towers_real()
     if not which or "step_c1" in which:
         gen_step_c1(ref_con, ref_cos)
+    if not which or "eval" in which:
+        gen_eval()
 
 
 if __name__ == "__main__":
