@@ -477,6 +477,32 @@ def mask_rows(x, count):
     return x
 
 
+# ------------------------------------------------------------------------------------------- crop front end
+
+def crop_resize(images_u8: torch.Tensor, dims: torch.Tensor, boxes: torch.Tensor, size: int,
+                max_crop_h: int, max_crop_w: int) -> torch.Tensor:
+    """images_u8 [B,Hmax,Wmax,3] uint8, dims [B,2] int32 (h,w), boxes [NR,5] int32 (b,x1,y1,x2,y2) -> [NR,3,S,S] fp32.
+    max_crop_h/w must bound the boxes' extents (the caller has the box list on the host anyway)."""
+    lib = _lib.load()
+    if not (images_u8.is_cuda and images_u8.dtype == torch.uint8 and images_u8.is_contiguous() and images_u8.dim() == 4
+            and images_u8.shape[3] == 3):
+        raise ValueError("crop_resize: images must be a contiguous uint8 CUDA tensor [B,H,W,3]")
+    B, Hmax, Wmax, _ = images_u8.shape
+    for t, n, shape in ((dims, "dims", (B, 2)), (boxes, "boxes", (boxes.shape[0], 5))):
+        if not (t.is_cuda and t.dtype == torch.int32 and t.is_contiguous() and tuple(t.shape) == shape):
+            raise ValueError(f"crop_resize: {n} must be a contiguous int32 CUDA tensor {shape}")
+    NR = boxes.shape[0]
+    if NR == 0 or max_crop_h <= 0 or max_crop_w <= 0:
+        raise ValueError("crop_resize: empty box list")
+    out = torch.empty((NR, 3, size, size), dtype=torch.float32, device=images_u8.device)
+    nbytes = lib.dclip_crop_resize_workspace(NR, size, max_crop_h, max_crop_w)
+    ws = _ws.get(nbytes, images_u8.device)
+    _lib.check(lib.dclip_crop_resize_u8(images_u8.data_ptr(), dims.data_ptr(), boxes.data_ptr(), out.data_ptr(), B, Hmax,
+                                        Wmax, NR, size, max_crop_h, max_crop_w, _ptr(ws), nbytes, _stream()),
+               "crop_resize_u8")
+    return out
+
+
 # ------------------------------------------------------------------------------------------- evaluation
 
 def rowdot_gather(a, b, idx=None):

@@ -239,6 +239,39 @@ class CLIPPatchTokenizer:
         arr = np.asarray(pil_patch.convert("RGB").resize((s, s), Image.BILINEAR), dtype=np.float32) / 255.0
         return torch.from_numpy(arr).permute(2, 0, 1).contiguous()
 
+    def crop_boxes_gpu(self, images: Sequence, boxes_per_image: Sequence[Sequence]) -> tuple:
+        """PIL images (or HWC uint8 arrays) + per-image box lists -> (regions [B,Rmax,3,S,S] in [0,1], counts [B]).
+        The crops are cut, resized and converted on the GPU, bit-exact with `patch_transform` (Pillow)."""
+        import numpy as np
+        dev = self.device
+        s = self.clip_model.config.vision.image_size
+        arrs = [np.asarray(im.convert("RGB") if hasattr(im, "convert") else im, dtype=np.uint8) for im in images]
+        B = len(arrs)
+        hmax, wmax = max(a.shape[0] for a in arrs), max(a.shape[1] for a in arrs)
+        batch = np.zeros((B, hmax, wmax, 3), dtype=np.uint8)
+        for b, a in enumerate(arrs):
+            batch[b, :a.shape[0], :a.shape[1]] = a
+        flat, counts = [], []
+        for b, boxes in enumerate(boxes_per_image):
+            counts.append(len(boxes))
+            for (x1, y1, x2, y2), _conf in boxes:
+                if x2 <= x1 or y2 <= y1:
+                    raise ValueError(f"degenerate box {(x1, y1, x2, y2)} (PIL cannot resize an empty crop either)")
+                flat.append((b, int(x1), int(y1), int(x2), int(y2)))
+        rmax = max(max(counts), 1)
+        regions = torch.zeros((B, rmax, 3, s, s), dtype=torch.float32, device=dev)
+        if flat:
+            bx = torch.tensor(flat, dtype=torch.int32)
+            crops = ops.crop_resize(torch.from_numpy(batch).to(dev), torch.tensor([a.shape[:2] for a in arrs], dtype=torch.int32
+                                                                                  ).to(dev), bx.to(dev), s,
+                                    int((bx[:, 4] - bx[:, 2]).max()), int((bx[:, 3] - bx[:, 1]).max()))
+            o = 0
+            for b, n in enumerate(counts):
+                if n:
+                    regions[b, :n] = crops[o:o + n]
+                    o += n
+        return regions, torch.tensor(counts, dtype=torch.int32)
+
     @torch.no_grad()
     def encode_regions(self, regions: torch.Tensor) -> torch.Tensor:
         """[N,3,S,S] in [0,1] -> [N,E] (one batched frozen forward)."""
@@ -330,26 +363,18 @@ class PatchTextAggregation(nn.Module):
 
     # ---- the reference's path-based signature
     def compute_global_embedding_batch(self, image_paths, texts, weighted_boxes_batch=None):
-        """:268-656 with cached boxes: crops are cut on the host (PIL) and everything after runs batched on the GPU."""
+        """:268-656 with cached boxes: images are decoded on the host; crops, resize and everything after run batched on the GPU."""
         from PIL import Image
         if weighted_boxes_batch is None:
             raise NotImplementedError("no detector here: pass weighted_boxes_batch (the reference's loader does)")
         if isinstance(weighted_boxes_batch, list):
             weighted_boxes_batch = dict(zip(image_paths, weighted_boxes_batch))
-        s = self._clip.config.vision.image_size
-        crops: List[List[torch.Tensor]] = []
+        images = []
         for path in image_paths:
             try:
-                image = Image.open(path).convert("RGB")
+                images.append(Image.open(path).convert("RGB"))
             except Exception:
-                image = Image.new("RGB", (224, 224))
-            crops.append([self.patch_tokenizer.patch_transform(image.crop(box))
-                          for box, _ in weighted_boxes_batch.get(path, [])])
-        counts = torch.tensor([len(c) for c in crops], dtype=torch.int32)
-        rmax = max(int(counts.max()), 1)
-        regions = torch.zeros(len(crops), rmax, 3, s, s)
-        for b, c in enumerate(crops):
-            if c:
-                regions[b, :len(c)] = torch.stack(c)
+                images.append(Image.new("RGB", (224, 224)))            # the reference's fallback (:302)
+        regions, counts = self.patch_tokenizer.crop_boxes_gpu(images, [weighted_boxes_batch.get(p, []) for p in image_paths])
         ids = self.text_tokenizer._ids(list(texts))
-        return self.compute_global_embedding_tensors(regions.to(self.device), ids, counts)
+        return self.compute_global_embedding_tensors(regions, ids, counts)

@@ -221,6 +221,20 @@ int dclip_rank_count(const float* queries, const float* candidates, const float*
                      int32_t* count, int Bq, int Bk, int P, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Region-crop front end: what training/image_tokenizer.py:100-110 does per box on the
+ * host with PIL — `image.crop(box)` (zero padding outside the image), `Resize((S,S))` (Pillow's antialiased
+ * two-pass BILINEAR in 8-bit fixed point) and `ToTensor()` (uint8/255, CHW, no mean/std) — for all boxes of a
+ * batch in three launches, bit-exact with Pillow 12.2.
+ *   images [B, Hmax, Wmax, 3] uint8 (HWC, each image in the top-left corner), dims [B,2] = (h, w),
+ *   boxes [NR,5] int32 = (image index, x1, y1, x2, y2) with x2 > x1, y2 > y1,  out [NR, 3, S, S] fp32.
+ *   max_crop_h / max_crop_w: the largest (y2-y1) / (x2-x1) in `boxes` (sizes the workspace and the tap count).
+ */
+size_t dclip_crop_resize_workspace(int NR, int S, int max_crop_h, int max_crop_w);
+int dclip_crop_resize_u8(const uint8_t* images, const int32_t* dims, const int32_t* boxes, float* out, int B,
+                         int Hmax, int Wmax, int NR, int S, int max_crop_h, int max_crop_w, void* workspace,
+                         size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Optimiser tail (pulled into the timed step).
  * sumsq / clip_coef: global-norm clipping as torch.nn.utils.clip_grad_norm_ does it, which is what Lightning's
  *   Trainer(gradient_clip_val=0.5) applies (training/CLIP_image_distill_training.py:41): each tensor writes
