@@ -234,12 +234,73 @@ __global__ void __launch_bounds__(256, 2) gemm_f32_kernel(GemmParams p) {
     }
   };
 
+  // unmasked registers -> LDS for ONE staged chunk (A chunks first, then B chunks)
+  auto store_chunk = [&](int buf, int c) {
+    if (c < A_CHUNKS) {
+      const int id = tid + c * 256;
+      float* a = As + buf * BM * BK;
+      if (A_KMAJOR) {
+        const int row = id >> 3, slot = id & 7;
+        *reinterpret_cast<f32x4*>(a + row * BK + ((slot ^ ((row >> 1) & 7)) << 2)) = ra[c];
+      } else {
+        *reinterpret_cast<f32x4*>(a + id * 4) = ra[c];
+      }
+    } else {
+      const int cb = c - A_CHUNKS;
+      const int id = tid + cb * 256;
+      float* b = Bs + buf * BN * BK;
+      if (B_KMAJOR) {
+        const int row = id >> 3, slot = id & 7;
+        *reinterpret_cast<f32x4*>(b + row * BK + ((slot ^ ((row >> 1) & 7)) << 2)) = rb[cb];
+      } else {
+        *reinterpret_cast<f32x4*>(b + id * 4) = rb[cb];
+      }
+    }
+  };
+
+  // Steady state (the next K-tile exists and is full): its global loads are issued behind the first fragment
+  // reads, and its LDS writes are spread one chunk per MFMA step over the second half of the running tile, so that
+  // after the tile's last MFMA only the barrier remains.
+  auto compute_and_stage = [&](int buf, int kt) {
+    const float* a = As + buf * BM * BK;
+    const float* b = Bs + buf * BN * BK;
+    constexpr int NCH = A_CHUNKS + B_CHUNKS;
+    constexpr int FIRST = 14 - NCH;  // MFMA steps FIRST .. FIRST+NCH-1 each carry one chunk store
+    f32x4 fa[2][MT], fb[2][NT];
+    read_frags(a, b, 0, fa[0], fb[0]);
+    load_tile(kt + 1);
+    __builtin_amdgcn_sched_barrier(0);  // keep the prefetch at the top: hipcc otherwise sinks the loads to their uses
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      if (g + 1 < 4) read_frags(a, b, g + 1, fa[(g + 1) & 1], fb[(g + 1) & 1]);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[g & 1][i][r], fb[g & 1][j][r], acc[i][j], 0, 0, 0);
+        const int step = g * 4 + r;
+        if (step >= FIRST && step - FIRST < NCH) {
+          store_chunk(buf ^ 1, step - FIRST);
+          __builtin_amdgcn_sched_barrier(0);  // one LDS write per MFMA step, in this order
+        }
+      }
+    }
+  };
+
   const bool k_ragged = (A_KMAJOR || B_KMAJOR) && (kspan % BK) != 0;  // only the last tile can be partial
   load_tile(0);
   if (k_ragged && nk == 1) store_tile(0, 0, true);
   else store_tile(0, 0, false);
   __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
+  int kt = 0;
+  const int n_steady = nk - 1 - (k_ragged ? 1 : 0);  // tiles whose successor is a full tile
+  for (; kt < n_steady; ++kt) {
+    compute_and_stage(kt & 1, kt);
+    __syncthreads();
+  }
+  for (; kt < nk; ++kt) {
     const int buf = kt & 1;
     if (kt + 1 < nk) load_tile(kt + 1);
     compute_tile(buf);
