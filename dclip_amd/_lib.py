@@ -61,6 +61,10 @@ SIGNATURES = {
     "dclip_sumsq_f32": (I, [P, Z, P, P]),
     "dclip_clip_coef": (I, [P, I, F, P, P, P]),
     "dclip_adamw_f32": (I, [P, P, P, P, Z, F, F, F, F, F, I, P, P]),
+    "dclip_mt_record_bytes": (I, []),
+    "dclip_mt_chunk_elems": (I, []),
+    "dclip_mt_sumsq_f32": (I, [P, I, I, P, P]),
+    "dclip_mt_adamw_f32": (I, [P, I, I, F, F, F, F, F, P, P]),
     "dclip_axpby": (I, [P, P, F, F, Z, P]),
     "dclip_fill": (I, [P, F, Z, P]),
 }

@@ -268,6 +268,7 @@ __global__ void __launch_bounds__(256, 2) gemm_f32_kernel(GemmParams p) {
     constexpr int FIRST = 14 - NCH;  // MFMA steps FIRST .. FIRST+NCH-1 each carry one chunk store
     f32x4 fa[2][MT], fb[2][NT];
     read_frags(a, b, 0, fa[0], fb[0]);
+    __builtin_amdgcn_sched_barrier(0);  // first fragments first: the MFMAs wait on them, not on the prefetch issue
     load_tile(kt + 1);
     __builtin_amdgcn_sched_barrier(0);  // keep the prefetch at the top: hipcc otherwise sinks the loads to their uses
 #pragma unroll

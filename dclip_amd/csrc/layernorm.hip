@@ -169,7 +169,7 @@ __global__ void __launch_bounds__(256) colsum_kernel(const float* __restrict__ X
 
 inline int ln_bwd_blocks(int rows) {
   int b = cdiv(rows, 4);
-  return b > 256 ? 256 : b;
+  return b > 1024 ? 1024 : b;  // 4 workgroups per CU keep enough rows in flight to stream at HBM rate
 }
 inline int colsum_splits(int M) {
   int s = cdiv(M, 128);

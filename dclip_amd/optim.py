@@ -1,9 +1,14 @@
 """`FusedAdamW`: torch.optim.AdamW semantics (the reference's optimizer, training/CLIP_image_distillation.py:680)
 with the update and the Trainer's global-norm clipping (gradient_clip_val=0.5,
 training/CLIP_image_distill_training.py:41) in the HIP library.  Subclasses torch.optim.Optimizer so that
-LR schedulers, state_dict() and the Lightning-style checkpoint layout keep working."""
+LR schedulers, state_dict() and the Lightning-style checkpoint layout keep working.
+
+Per step and per parameter group: ONE multi-tensor sum-of-squares launch, one clip-coefficient launch (the
+coefficient stays on the device — no host sync) and ONE multi-tensor AdamW launch.  The table of tensor records is
+rebuilt on the host each step (gradients are fresh tensors every backward) and uploaded with one small copy."""
 from __future__ import annotations
 
+import struct
 from typing import Optional
 
 import torch
@@ -19,51 +24,72 @@ class FusedAdamW(torch.optim.Optimizer):
         self.max_grad_norm = max_grad_norm
         self._partials = None
         self._coef = None
+        self._table = {}
         self.last_grad_norm = None
 
-    def _clip_coef(self, stream):
-        """Device-side clip coefficient over every parameter that has a gradient (no host sync)."""
+    def _records(self, group, gi):
+        """(device table, ntensors, total_chunks, grads kept alive) for one parameter group."""
         lib = _lib.load()
-        ps = [p for g in self.param_groups for p in g["params"] if p.grad is not None]
-        dev = ps[0].device
-        counts = [lib.dclip_sumsq_blocks(p.grad.numel()) for p in ps]
-        total = sum(counts)
-        if self._partials is None or self._partials.numel() < total:
-            self._partials = torch.empty(total, dtype=torch.float32, device=dev)
-            self._coef = torch.empty(2, dtype=torch.float32, device=dev)
-        o = 0
-        for p, c in zip(ps, counts):
+        chunk = lib.dclip_mt_chunk_elems()
+        assert lib.dclip_mt_record_bytes() == 48
+        recs, keep, c0 = [], [], 0
+        for p in group["params"]:
+            if p.grad is None:
+                continue
+            if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()):
+                raise ValueError("FusedAdamW: contiguous float32 CUDA parameters only")
+            st = self.state[p]
+            if not st:
+                st["step"] = 0
+                st["exp_avg"] = torch.zeros_like(p)
+                st["exp_avg_sq"] = torch.zeros_like(p)
+            st["step"] += 1
             g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
-            _lib.check(lib.dclip_sumsq_f32(g.data_ptr(), g.numel(), self._partials.data_ptr() + 4 * o, stream), "sumsq")
-            o += c
-        _lib.check(lib.dclip_clip_coef(self._partials.data_ptr(), total, float(self.max_grad_norm),
-                                       self._coef.data_ptr(), self._coef.data_ptr() + 4, stream), "clip_coef")
-        self.last_grad_norm = self._coef[1]
-        return self._coef
+            keep.append(g)
+            n = p.numel()
+            recs.append(struct.pack("<QQQQQii", p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(),
+                                    st["exp_avg_sq"].data_ptr(), n, int(st["step"]), c0))
+            c0 += (n + chunk - 1) // chunk
+        if not recs:
+            return None
+        blob = b"".join(recs)
+        host = self._table.get(gi)
+        if host is None or host[0].numel() < len(blob):
+            host = (torch.empty(len(blob), dtype=torch.uint8).pin_memory(),
+                    torch.empty(len(blob), dtype=torch.uint8, device=keep[0].device))
+            self._table[gi] = host
+        host[0][:len(blob)].copy_(torch.frombuffer(bytearray(blob), dtype=torch.uint8))
+        host[1][:len(blob)].copy_(host[0][:len(blob)], non_blocking=True)
+        return host[1], len(recs), c0, keep
 
     @torch.no_grad()
     def step(self, closure=None):
         loss = closure() if closure is not None else None
         lib = _lib.load()
         stream = torch.cuda.current_stream().cuda_stream
-        coef = self._clip_coef(stream) if self.max_grad_norm else None
-        for group in self.param_groups:
+        tables = [(g, self._records(g, gi)) for gi, g in enumerate(self.param_groups)]
+        tables = [(g, t) for g, t in tables if t is not None]
+        if not tables:
+            return loss
+        coef = None
+        if self.max_grad_norm:
+            total = sum(t[2] for _, t in tables)
+            dev = tables[0][1][0].device
+            if self._partials is None or self._partials.numel() < total:
+                self._partials = torch.empty(total, dtype=torch.float32, device=dev)
+                self._coef = torch.empty(2, dtype=torch.float32, device=dev)
+            o = 0
+            for _, (tab, nt, nchunks, _keep) in tables:
+                _lib.check(lib.dclip_mt_sumsq_f32(tab.data_ptr(), nt, nchunks, self._partials.data_ptr() + 4 * o, stream),
+                           "mt_sumsq")
+                o += nchunks
+            _lib.check(lib.dclip_clip_coef(self._partials.data_ptr(), total, float(self.max_grad_norm),
+                                           self._coef.data_ptr(), self._coef.data_ptr() + 4, stream), "clip_coef")
+            self.last_grad_norm = self._coef[1]
+            coef = self._coef
+        for group, (tab, nt, nchunks, _keep) in tables:
             b1, b2 = group["betas"]
-            for p in group["params"]:
-                if p.grad is None:
-                    continue
-                if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()):
-                    raise ValueError("FusedAdamW: contiguous float32 CUDA parameters only")
-                st = self.state[p]
-                if not st:
-                    st["step"] = 0
-                    st["exp_avg"] = torch.zeros_like(p)
-                    st["exp_avg_sq"] = torch.zeros_like(p)
-                st["step"] += 1
-                g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
-                _lib.check(lib.dclip_adamw_f32(p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(),
-                                               st["exp_avg_sq"].data_ptr(), p.numel(), float(group["lr"]), float(b1),
-                                               float(b2), float(group["eps"]), float(group["weight_decay"]),
-                                               int(st["step"]), None if coef is None else coef.data_ptr(), stream),
-                           "adamw")
+            _lib.check(lib.dclip_mt_adamw_f32(tab.data_ptr(), nt, nchunks, float(group["lr"]), float(b1), float(b2),
+                                              float(group["eps"]), float(group["weight_decay"]),
+                                              None if coef is None else coef.data_ptr(), stream), "mt_adamw")
         return loss

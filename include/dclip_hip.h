@@ -249,6 +249,16 @@ int dclip_sumsq_f32(const float* x, size_t n, float* partial, void* stream);
 int dclip_clip_coef(const float* partial, int n, float max_norm, float* coef, float* norm_out, void* stream);
 int dclip_adamw_f32(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2,
                     float eps, float weight_decay, int step, const float* grad_scale, void* stream);
+/* Multi-tensor forms: ONE launch for all parameters of a group.  `refs` is a DEVICE array of `ntensors` records of
+ * dclip_mt_record_bytes() bytes each: { float* p; const float* g; float* m; float* v; uint64_t n; int32_t step;
+ * int32_t chunk0; } where chunk0 is the running sum of ceil(n / dclip_mt_chunk_elems()) over the preceding
+ * tensors and total_chunks the sum over all.  mt_sumsq writes one partial per chunk (feed them to dclip_clip_coef);
+ * mt_adamw applies the update of dclip_adamw_f32 to every tensor. */
+int dclip_mt_record_bytes(void);
+int dclip_mt_chunk_elems(void);
+int dclip_mt_sumsq_f32(const void* refs, int ntensors, int total_chunks, float* partial, void* stream);
+int dclip_mt_adamw_f32(const void* refs, int ntensors, int total_chunks, float lr, float beta1, float beta2,
+                       float eps, float weight_decay, const float* grad_scale, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Small elementwise helpers used between the ops above (all fp32, 16-byte vectorised).
