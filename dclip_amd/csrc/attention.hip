@@ -359,6 +359,135 @@ __global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(AttnArgs a, const flo
   }
 }
 
+// ------------------------------------------------------------------------------------------- backward, one tile
+// Self-attention with S <= 64 (ViT-B/32: S = 50): the whole (batch, head) problem is one tile, so S/P/dP/dS are
+// formed ONCE and dQ, dK, dV all come out of one workgroup — 5 MFMA products instead of the 7 of the two-kernel
+// path, q/k/v/dO read once.  P and dS live in LDS as ordinary swizzled tiles: read by rows (ds_read_b128) they are
+// the A operand of dQ = dS K, read by columns (ds_read_b32) they are the A operand of dV = P^T dO and dK = dS^T Q.
+// LDS: Q, K, V, dO, P tiles + dS aliased onto V (dead after dP) = 5 x 16 KiB = 80 KiB -> two workgroups per CU.
+
+// acc[nt] += A[rbase + (lane&15)][k] * B[k][16nt + (lane&15)], A by rows of a swizzled tile, B a swizzled tile
+__device__ __forceinline__ void mma_tilerows_x_tile(f32x4 (&acc)[4], const float* atile, int rbase, const float* btile,
+                                                    int lane) {
+  const int qd = lane >> 4, l15 = lane & 15;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    f32x4 af = frag_k(atile, rbase, g, lane);
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[r], btile[tile_off(16 * g + 4 * qd + r, 16 * nt + l15)], acc[nt], 0,
+                                                       0, 0);
+  }
+}
+
+// acc[nt] += A[k][cbase + (lane&15)] * B[k][16nt + (lane&15)]   (A transposed on the fly: column reads)
+__device__ __forceinline__ void mma_tilecols_x_tile(f32x4 (&acc)[4], const float* atile, int cbase, const float* btile,
+                                                    int lane) {
+  const int qd = lane >> 4, l15 = lane & 15;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    float af[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) af[r] = atile[tile_off(16 * g + 4 * qd + r, cbase + l15)];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[r], btile[tile_off(16 * g + 4 * qd + r, 16 * nt + l15)], acc[nt], 0,
+                                                       0, 0);
+  }
+}
+
+template <bool CAUSAL>
+__global__ void __launch_bounds__(256, 2) attn_bwd_fused_kernel(AttnArgs a, const float* __restrict__ out,
+                                                                const float* __restrict__ dout, const float* __restrict__ lse,
+                                                                float* __restrict__ dq_out, float* __restrict__ dk_out,
+                                                                float* __restrict__ dv_out, int ldd) {
+  __shared__ __attribute__((aligned(16))) float lds[5 * TS * HD];
+  float* Qs = lds;
+  float* Ks = lds + TS * HD;
+  float* Vs = lds + 2 * TS * HD;
+  float* dOs = lds + 3 * TS * HD;
+  float* Ps = lds + 4 * TS * HD;
+  float* dSs = Vs;  // V is dead once dP = dO V^T has been formed
+  const int H = a.H, S = a.Sk;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int qd = lane >> 4, l15 = lane & 15;
+  const int bh = blockIdx.x, b = bh / H, h = bh % H;
+  const int D = H * HD;
+  const float* qbase = a.q + (size_t)b * S * a.ldq + h * HD;
+  const float* kbase = a.k + (size_t)b * S * a.ldkv + h * HD;
+  const float* vbase = a.v + (size_t)b * S * a.ldkv + h * HD;
+  const float* obase = out + (size_t)b * S * D + h * HD;
+  const float* dobase = dout + (size_t)b * S * D + h * HD;
+
+  stage_tile(Qs, qbase, 0, S, (size_t)a.ldq);
+  stage_tile(Ks, kbase, 0, S, (size_t)a.ldkv);
+  stage_tile(Vs, vbase, 0, S, (size_t)a.ldkv);
+  stage_tile(dOs, dobase, 0, S, (size_t)D);
+  // delta and lse for this lane's 4 query rows (rows 16*wave + 4*qd + r): 16 lanes share a row -> each sums 4 floats
+  float dl[4], lse_r[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = 16 * wave + 4 * qd + r;
+    float s = 0.f;
+    if (row < S) {
+      f32x4 o4 = *reinterpret_cast<const f32x4*>(obase + (size_t)row * D + l15 * 4);
+      f32x4 d4 = *reinterpret_cast<const f32x4*>(dobase + (size_t)row * D + l15 * 4);
+      s = (o4[0] * d4[0] + o4[1] * d4[1]) + (o4[2] * d4[2] + o4[3] * d4[3]);
+    }
+    dl[r] = quarter_sum(s);
+    lse_r[r] = (row < S) ? lse[(size_t)bh * S + row] : 0.f;
+  }
+  __syncthreads();
+  f32x4 qf[4], dof[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    qf[g] = frag_k(Qs, 16 * wave, g, lane);
+    dof[g] = frag_k(dOs, 16 * wave, g, lane);
+  }
+  f32x4 s[4], dp[4];
+  zero4(s);
+  zero4(dp);
+  mma_rows_x_tileT(s, qf, Ks, lane);
+  mma_rows_x_tileT(dp, dof, Vs, lane);
+  __syncthreads();  // every wave is done reading V before dS overwrites it
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) {
+    const int key = nt * 16 + l15;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int qrow = 16 * wave + 4 * qd + r;
+      const bool masked = key >= S || qrow >= S || (CAUSAL && key > qrow);
+      const float p = masked ? 0.f : __expf(s[nt][r] * kScale - lse_r[r]);
+      Ps[tile_off(qrow, key)] = p;
+      dSs[tile_off(qrow, key)] = p * (dp[nt][r] - dl[r]) * kScale;
+    }
+  }
+  __syncthreads();
+  f32x4 dq[4], dk[4], dv[4];
+  zero4(dq);
+  zero4(dk);
+  zero4(dv);
+  mma_tilerows_x_tile(dq, dSs, 16 * wave, Ks, lane);   // dQ[q rows of this wave]   = dS K
+  mma_tilecols_x_tile(dv, Ps, 16 * wave, dOs, lane);   // dV[key rows of this wave] = P^T dO
+  mma_tilecols_x_tile(dk, dSs, 16 * wave, Qs, lane);   // dK[key rows of this wave] = dS^T Q
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = 16 * wave + 4 * qd + r;
+    if (row < S)
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        const size_t o = ((size_t)b * S + row) * ldd + h * HD + nt * 16 + l15;
+        dq_out[o] = dq[nt][r];
+        dk_out[o] = dk[nt][r];
+        dv_out[o] = dv[nt][r];
+      }
+  }
+}
+
 }  // namespace
 
 namespace {
@@ -374,6 +503,12 @@ int launch_fwd(const AttnArgs& a, float* out, float* lse, int B, int causal, hip
 int launch_bwd(const AttnArgs& a, const float* out, const float* dout, const float* lse, float* dq, int lddq, float* dk,
                float* dv, int lddkv, float* delta, int B, int causal, hipStream_t st) {
   dim3 gq(B * a.H, cdiv(a.Sq, TS)), gk(B * a.H, cdiv(a.Sk, TS)), block(256);
+  if (a.Sq == a.Sk && a.Sq <= TS && lddq == lddkv) {  // one-tile self-attention: fused dQ/dK/dV
+    if (causal) hipLaunchKernelGGL((attn_bwd_fused_kernel<true>), dim3(B * a.H), block, 0, st, a, out, dout, lse, dq, dk, dv, lddq);
+    else hipLaunchKernelGGL((attn_bwd_fused_kernel<false>), dim3(B * a.H), block, 0, st, a, out, dout, lse, dq, dk, dv, lddq);
+    DCLIP_CHECK_LAUNCH("attention_bwd.fused");
+    return DCLIP_OK;
+  }
   if (causal) {
     hipLaunchKernelGGL((attn_bwd_dq_kernel<true>), gq, block, 0, st, a, out, dout, lse, dq, lddq, delta);
     hipLaunchKernelGGL((attn_bwd_dkv_kernel<true>), gk, block, 0, st, a, dout, lse, delta, dk, dv, lddkv);
