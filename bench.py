@@ -247,9 +247,14 @@ def main():
                          "launches_per_step": glaunches // max(1, args.steps),
                          "gemm_ms_per_step": round(gms / max(1, args.steps), 3),
                          "gemm_flops_per_step": gflops / max(1, args.steps)},
+            # whole step priced two ways: `frac` with the ALGORITHMIC flops of the reference's arithmetic (SURVEY §8d:
+            # 3 F_vis + F_txt per image), `frac_executed` with the GEMM flops actually launched — lower because the last
+            # vision layer is evaluated on the CLS rows only, which is exact ("dead-row elimination")
             "roofline_step": {"bound": "mfma", "achieved": round(step_flops / (ms_per_step * 1e-3) / 1e12, 2),
                               "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                               "frac": round(step_flops / (ms_per_step * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                              "frac_executed": None if not gms else round(
+                                  gflops / max(1, args.steps) / (ms_per_step * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
                               "flops_per_image": step_flops_per_image(cfg, T)},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -73,6 +73,40 @@ __device__ __forceinline__ void mma_scratch_x_tile(f32x4 (&acc)[4], const float*
   }
 }
 
+// acc[nt] += A[rbase + (lane&15)][k] * B[k][16nt + (lane&15)], A by rows of a swizzled tile, B a swizzled tile
+__device__ __forceinline__ void mma_tilerows_x_tile(f32x4 (&acc)[4], const float* atile, int rbase, const float* btile,
+                                                    int lane) {
+  const int qd = lane >> 4, l15 = lane & 15;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    f32x4 af = frag_k(atile, rbase, g, lane);
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[r], btile[tile_off(16 * g + 4 * qd + r, 16 * nt + l15)], acc[nt], 0,
+                                                       0, 0);
+  }
+}
+
+// acc[nt] += A[k][cbase + (lane&15)] * B[k][16nt + (lane&15)]   (A transposed on the fly: column reads)
+__device__ __forceinline__ void mma_tilecols_x_tile(f32x4 (&acc)[4], const float* atile, int cbase, const float* btile,
+                                                    int lane) {
+  const int qd = lane >> 4, l15 = lane & 15;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    float af[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) af[r] = atile[tile_off(16 * g + 4 * qd + r, cbase + l15)];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[r], btile[tile_off(16 * g + 4 * qd + r, 16 * nt + l15)], acc[nt], 0,
+                                                       0, 0);
+  }
+}
+
 __device__ __forceinline__ void zero4(f32x4 (&a)[4]) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) a[i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -92,9 +126,12 @@ struct AttnArgs {
 template <bool CAUSAL>
 __global__ void __launch_bounds__(256) attn_fwd_kernel(AttnArgs a, float* __restrict__ out, float* __restrict__ lse) {
   const int H = a.H, S = a.Sk, Sq = a.Sq;
-  __shared__ __attribute__((aligned(16))) float t0[TS * HD];
-  __shared__ __attribute__((aligned(16))) float t1[TS * HD];
-  __shared__ __attribute__((aligned(16))) float scratch[4 * 16 * SCR];
+  // Q, K, V tiles.  Once a wave holds its Q fragments in registers, its 16 rows of the Q tile become its private P
+  // scratch (only that wave ever touches those rows), so P needs no extra LDS and no workgroup barrier.
+  __shared__ __attribute__((aligned(16))) float lds[3 * TS * HD];
+  float* Qs = lds;
+  float* Ks = lds + TS * HD;
+  float* Vs = lds + 2 * TS * HD;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int qd = lane >> 4, l15 = lane & 15;
   const int bh = blockIdx.x, b = bh / H, h = bh % H;
@@ -103,13 +140,14 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(AttnArgs a, float* __rest
   const float* qbase = a.q + (size_t)b * Sq * a.ldq + h * HD;
   const float* kbase = a.k + (size_t)b * S * a.ldkv + h * HD;
   const float* vbase = a.v + (size_t)b * S * a.ldkv + h * HD;
-  float* scr = scratch + wave * 16 * SCR;
 
-  stage_tile(t0, qbase, q0, Sq, (size_t)a.ldq);
+  stage_tile(Qs, qbase, q0, Sq, (size_t)a.ldq);
+  stage_tile(Ks, kbase, 0, S, (size_t)a.ldkv);
+  stage_tile(Vs, vbase, 0, S, (size_t)a.ldkv);
   __syncthreads();
   f32x4 qf[4];
 #pragma unroll
-  for (int g = 0; g < 4; ++g) qf[g] = frag_k(t0, 16 * wave, g, lane);
+  for (int g = 0; g < 4; ++g) qf[g] = frag_k(Qs, 16 * wave, g, lane);
 
   float m[4], l[4];
   f32x4 o[4];
@@ -122,13 +160,15 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(AttnArgs a, float* __rest
   int nkt = (S + TS - 1) / TS;
   if (CAUSAL) nkt = min(nkt, (int)blockIdx.y + 1);
   for (int kt = 0; kt < nkt; ++kt) {
-    __syncthreads();  // everyone is done with t0/t1 of the previous tile (and with the Q fragments load)
-    stage_tile(t0, kbase, kt * TS, S, (size_t)a.ldkv);
-    stage_tile(t1, vbase, kt * TS, S, (size_t)a.ldkv);
-    __syncthreads();
+    if (kt > 0) {
+      __syncthreads();  // everyone is done with the previous K/V tile
+      stage_tile(Ks, kbase, kt * TS, S, (size_t)a.ldkv);
+      stage_tile(Vs, vbase, kt * TS, S, (size_t)a.ldkv);
+      __syncthreads();
+    }
     f32x4 s[4];
     zero4(s);
-    mma_rows_x_tileT(s, qf, t0, lane);
+    mma_rows_x_tileT(s, qf, Ks, lane);
     float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
@@ -163,11 +203,10 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(AttnArgs a, float* __rest
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) {
         o[nt][r] *= alpha[r];
-        scr[(4 * qd + r) * SCR + nt * 16 + l15] = s[nt][r];
+        Qs[tile_off(16 * wave + 4 * qd + r, nt * 16 + l15)] = s[nt][r];   // this wave's private rows
       }
     }
-    __syncthreads();
-    mma_scratch_x_tile(o, scr, t1, lane);
+    mma_tilerows_x_tile(o, Qs, 16 * wave, Vs, lane);
   }
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
@@ -366,40 +405,6 @@ __global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(AttnArgs a, const flo
 // the A operand of dQ = dS K, read by columns (ds_read_b32) they are the A operand of dV = P^T dO and dK = dS^T Q.
 // LDS: Q, K, V, dO, P tiles + dS aliased onto V (dead after dP) = 5 x 16 KiB = 80 KiB -> two workgroups per CU.
 
-// acc[nt] += A[rbase + (lane&15)][k] * B[k][16nt + (lane&15)], A by rows of a swizzled tile, B a swizzled tile
-__device__ __forceinline__ void mma_tilerows_x_tile(f32x4 (&acc)[4], const float* atile, int rbase, const float* btile,
-                                                    int lane) {
-  const int qd = lane >> 4, l15 = lane & 15;
-#pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    f32x4 af = frag_k(atile, rbase, g, lane);
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[r], btile[tile_off(16 * g + 4 * qd + r, 16 * nt + l15)], acc[nt], 0,
-                                                       0, 0);
-  }
-}
-
-// acc[nt] += A[k][cbase + (lane&15)] * B[k][16nt + (lane&15)]   (A transposed on the fly: column reads)
-__device__ __forceinline__ void mma_tilecols_x_tile(f32x4 (&acc)[4], const float* atile, int cbase, const float* btile,
-                                                    int lane) {
-  const int qd = lane >> 4, l15 = lane & 15;
-#pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    float af[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) af[r] = atile[tile_off(16 * g + 4 * qd + r, cbase + l15)];
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[r], btile[tile_off(16 * g + 4 * qd + r, 16 * nt + l15)], acc[nt], 0,
-                                                       0, 0);
-  }
-}
-
 template <bool CAUSAL>
 __global__ void __launch_bounds__(256, 2) attn_bwd_fused_kernel(AttnArgs a, const float* __restrict__ out,
                                                                 const float* __restrict__ dout, const float* __restrict__ lse,
@@ -538,6 +543,27 @@ DCLIP_API int dclip_attention_bwd(const float* qkv, const float* out, const floa
   const int D = H * HD;
   AttnArgs a{qkv, qkv + D, qkv + 2 * D, 3 * D, 3 * D, S, S, H};
   return launch_bwd(a, out, dout, lse, dqkv, 3 * D, dqkv + D, dqkv + 2 * D, 3 * D, delta, B, causal, (hipStream_t)stream);
+}
+
+// Last-layer pruning: after the final encoder layer only the CLS row of every image is used (hf:modeling_clip.py:650),
+// so the last layer's attention is needed for ONE query row per (image, head) — against all keys.  Same kernels:
+// the query "sequence" is row 0 of each image (Sq = 1, batch stride S*3D inside the fused projection).
+DCLIP_API int dclip_attention_cls_fwd(const float* qkv, float* out, float* lse, int B, int S, int H, void* stream) {
+  DCLIP_REQUIRE(qkv && out && lse, "attention_cls_fwd: null pointer");
+  DCLIP_REQUIRE(B > 0 && S > 0 && H > 0, "attention_cls_fwd: bad shape");
+  const int D = H * HD;
+  AttnArgs a{qkv, qkv + D, qkv + 2 * D, S * 3 * D, 3 * D, 1, S, H};
+  return launch_fwd(a, out, lse, B, 0, (hipStream_t)stream);
+}
+
+// dqkv must be zero-filled by the caller where this call does not write (the q part of every non-CLS row).
+DCLIP_API int dclip_attention_cls_bwd(const float* qkv, const float* out, const float* dout, const float* lse, float* dqkv,
+                                      float* delta, int B, int S, int H, void* stream) {
+  DCLIP_REQUIRE(qkv && out && dout && lse && dqkv && delta, "attention_cls_bwd: null pointer");
+  DCLIP_REQUIRE(B > 0 && S > 0 && H > 0, "attention_cls_bwd: bad shape");
+  const int D = H * HD;
+  AttnArgs a{qkv, qkv + D, qkv + 2 * D, S * 3 * D, 3 * D, 1, S, H};
+  return launch_bwd(a, out, dout, lse, dqkv, S * 3 * D, dqkv + D, dqkv + 2 * D, 3 * D, delta, B, 0, (hipStream_t)stream);
 }
 
 DCLIP_API int dclip_cross_attention_fwd(const float* q, const float* kv, float* out, float* lse, int B, int Lq, int Lk,

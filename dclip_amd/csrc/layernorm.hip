@@ -125,21 +125,23 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const float* __restrict__ d
   }
 }
 
-// out[n] (+)= sum_p partial[p][n]   (fixed order -> deterministic).  Block = 64 columns x 4 row groups.
-__global__ void __launch_bounds__(256) reduce_partials_kernel(const float* __restrict__ partial, float* __restrict__ out0,
-                                                              float* __restrict__ out1, int P, int N0, int N1,
-                                                              int accumulate) {
-  __shared__ float red[4][64];
+// out[n] (+)= sum_p partial[p][n]   (fixed order -> deterministic).  Block = 64 columns x 16 row groups.
+__global__ void __launch_bounds__(1024) reduce_partials_kernel(const float* __restrict__ partial, float* __restrict__ out0,
+                                                               float* __restrict__ out1, int P, int N0, int N1,
+                                                               int accumulate) {
+  __shared__ float red[16][64];
   const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
   const int n = blockIdx.x * 64 + cl;
   const int N = N0 + N1;
   float s = 0.f;
   if (n < N)
-    for (int p = rg; p < P; p += 4) s += partial[(size_t)p * N + n];
+    for (int p = rg; p < P; p += 16) s += partial[(size_t)p * N + n];
   red[rg][cl] = s;
   __syncthreads();
   if (rg != 0 || n >= N) return;
-  s = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
+  s = 0.f;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) s += red[k][cl];
   float* base = (n < N0) ? out0 : out1;
   if (!base) return;
   float* o = base + ((n < N0) ? n : n - N0);
@@ -228,7 +230,7 @@ DCLIP_API int dclip_layernorm_bwd(const float* dy, const float* x, const float* 
 #undef LN_BWD
   DCLIP_CHECK_LAUNCH("layernorm_bwd");
   if (want_params) {
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(2 * D, 64)), dim3(256), 0, st, partial, dgamma, dbeta, blocks, D,
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(2 * D, 64)), dim3(1024), 0, st, partial, dgamma, dbeta, blocks, D,
                        D, accumulate_param_grads);
     DCLIP_CHECK_LAUNCH("layernorm_bwd.reduce");
   }
@@ -249,7 +251,7 @@ DCLIP_API int dclip_colsum_f32(const float* X, float* out, int M, int N, int ldx
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(N / 4, 64), splits), dim3(256), 0, st, X, (float*)workspace, M, N, ldx);
   DCLIP_CHECK_LAUNCH("colsum");
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(N, 64)), dim3(256), 0, st, (const float*)workspace, out,
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(N, 64)), dim3(1024), 0, st, (const float*)workspace, out,
                      (float*)nullptr, splits, N, 0, accumulate);
   DCLIP_CHECK_LAUNCH("colsum.reduce");
   return DCLIP_OK;

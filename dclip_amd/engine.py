@@ -92,6 +92,69 @@ def layer_bwd(dx2, p: LayerParams, saved, B: int, S: int, H: int, causal: bool, 
     return dx, gr
 
 
+# --------------------------------------------------------------------------------------------- last vision layer
+# After the final encoder layer the model reads ONLY the CLS row of each image (hf:modeling_clip.py:650-651).  In
+# that layer everything downstream of the attention — out_proj, LayerNorm2, fc1, quick-GELU, fc2 and both residual
+# adds — is row-wise, so it is evaluated for the B CLS rows instead of all B*S rows, and the attention itself for
+# one query row per (image, head).  In the backward the incoming gradient is nonzero only on those rows, so the
+# same restriction is exact there too (the other rows' contributions to every weight gradient are products with
+# zero).  K and V, hence the qkv projection, LayerNorm1 and their gradients, stay full size.  Results are identical
+# to the unpruned schedule (tests/test_model_gpu.py); 9/12 of that layer's GEMM work disappears.
+
+def last_layer_fwd_cls(x, p: LayerParams, B: int, S: int, H: int, eps: float, save: bool):
+    D = x.shape[1]
+    ln1, m1, r1 = ops.layernorm_fwd(x, p.ln1_w, p.ln1_b, eps, save_stats=save)
+    qkv = ops.gemm(ln1, p.qkv_w, ops.LAYOUT_NT, bias=p.qkv_b)
+    attn, lse = ops.attention_cls_fwd(qkv, B, S, H)                       # [B, D]
+    x_cls = ops.gather_rows(x, None, B, S, D)
+    x1 = ops.gemm(attn, p.out_w, ops.LAYOUT_NT, bias=p.out_b, residual=x_cls)
+    ln2, m2, r2 = ops.layernorm_fwd(x1, p.ln2_w, p.ln2_b, eps, save_stats=save)
+    h = torch.empty((B, p.fc1_w.shape[0]), dtype=torch.float32, device=x.device) if save else None
+    g = ops.gemm(ln2, p.fc1_w, ops.LAYOUT_NT, bias=p.fc1_b, aux=h, epilogue=ops.EPI_GELU)
+    x2 = ops.gemm(g, p.fc2_w, ops.LAYOUT_NT, bias=p.fc2_b, residual=x1)   # [B, D] = final hidden state, CLS rows
+    saved = (x, m1, r1, ln1, qkv, attn, lse, x1, m2, r2, ln2, h, g) if save else None
+    return x2, saved
+
+
+def last_layer_bwd_cls(dx2, p: LayerParams, saved, B: int, S: int, H: int, need: Dict[str, bool]):
+    """dx2 [B, D] is the gradient w.r.t. the CLS rows of the final hidden state; returns (dx [B*S, D], grads)."""
+    x, m1, r1, ln1, qkv, attn, lse, x1, m2, r2, ln2, h, g = saved
+    D = x.shape[1]
+    gr: Dict[str, torch.Tensor] = {}
+    if need.get("fc2_w"):
+        gr["fc2_w"] = ops.gemm(dx2, g, ops.LAYOUT_TN)
+    if need.get("fc2_b"):
+        gr["fc2_b"] = ops.colsum(dx2)
+    dh = ops.gemm(dx2, p.fc2_w, ops.LAYOUT_NN, aux=h, epilogue=ops.EPI_DGELU)
+    if need.get("fc1_w"):
+        gr["fc1_w"] = ops.gemm(dh, ln2, ops.LAYOUT_TN)
+    if need.get("fc1_b"):
+        gr["fc1_b"] = ops.colsum(dh)
+    dln2 = ops.gemm(dh, p.fc1_w, ops.LAYOUT_NN)
+    want_ln2 = bool(need.get("ln2_w") or need.get("ln2_b"))
+    dx1, dg, db = ops.layernorm_bwd(dln2, x1, p.ln2_w, m2, r2, dresidual=dx2, need_param_grads=want_ln2)
+    if want_ln2:
+        gr["ln2_w"], gr["ln2_b"] = dg, db
+    if need.get("out_w"):
+        gr["out_w"] = ops.gemm(dx1, attn, ops.LAYOUT_TN)
+    if need.get("out_b"):
+        gr["out_b"] = ops.colsum(dx1)
+    dattn = ops.gemm(dx1, p.out_w, ops.LAYOUT_NN)
+    dqkv = ops.attention_cls_bwd(qkv, attn, dattn, lse, B, S, H)          # [B*S, 3D]; d q only on the CLS rows
+    if need.get("qkv_w"):
+        gr["qkv_w"] = ops.gemm(dqkv, ln1, ops.LAYOUT_TN)
+    if need.get("qkv_b"):
+        gr["qkv_b"] = ops.colsum(dqkv)
+    dln1 = ops.gemm(dqkv, p.qkv_w, ops.LAYOUT_NN)
+    del dqkv
+    want_ln1 = bool(need.get("ln1_w") or need.get("ln1_b"))
+    dres = ops.scatter_rows(dx1, None, B, S, D)                           # the skip connection carries dx1 on CLS rows only
+    dx, dg, db = ops.layernorm_bwd(dln1, x, p.ln1_w, m1, r1, dresidual=dres, need_param_grads=want_ln1)
+    if want_ln1:
+        gr["ln1_w"], gr["ln1_b"] = dg, db
+    return dx, gr
+
+
 # --------------------------------------------------------------------------------------------- vision tower
 
 @dataclass
@@ -144,22 +207,28 @@ def vision_fwd(p: VisionParams, pixel_values: torch.Tensor, cfg, save: bool, hid
     if hidden_out is not None:
         hidden_out.append(x)
     saved_layers = []
-    for lp in p.layers:
+    prune = hidden_out is None and len(p.layers) > 0          # full hidden states are only materialised on request
+    for li, lp in enumerate(p.layers):
+        if prune and li == len(p.layers) - 1:
+            cls_tok, sv = last_layer_fwd_cls(x, lp, B, S, H, v.layer_norm_eps, save)
+            saved_layers.append(sv)
+            break
         x, sv = layer_fwd(x, lp, B, S, H, False, v.layer_norm_eps, save)
         saved_layers.append(sv)
         if hidden_out is not None:
             hidden_out.append(x)
-    cls_tok = ops.gather_rows(x, None, B, S, D)
+    if not prune:
+        cls_tok = ops.gather_rows(x, None, B, S, D)
     pooled, mp, rp = ops.layernorm_fwd(cls_tok, p.post_w, p.post_b, v.layer_norm_eps, save_stats=save)
     out = ops.gemm(pooled, p.proj_w, ops.LAYOUT_NT)
-    saved = (cols, emb, m0, r0, saved_layers, cls_tok, mp, rp, pooled) if save else None
+    saved = (cols, emb, m0, r0, saved_layers, cls_tok, mp, rp, pooled, prune) if save else None
     return out, saved
 
 
 def vision_bwd(p: VisionParams, saved, d_out: torch.Tensor, cfg, need: List[bool]):
     """Gradients for VisionParams.tensors() order (None where not needed)."""
     v = cfg
-    cols, emb, m0, r0, saved_layers, cls_tok, mp, rp, pooled = saved
+    cols, emb, m0, r0, saved_layers, cls_tok, mp, rp, pooled, pruned = saved
     B = cls_tok.shape[0]
     S, D, H = v.seq_len, v.hidden_size, v.num_attention_heads
     names = p.names()
@@ -172,7 +241,6 @@ def vision_bwd(p: VisionParams, saved, d_out: torch.Tensor, cfg, need: List[bool
     dcls, dg, db = ops.layernorm_bwd(dpooled, cls_tok, p.post_w, mp, rp, need_param_grads=want)
     if want:
         grads["post_w"], grads["post_b"] = dg, db
-    dx = ops.scatter_rows(dcls, None, B, S, D)
     n_layers = len(p.layers)
     # stop as soon as nothing below still needs a gradient (e.g. only visual_projection trainable)
     lowest = None
@@ -182,9 +250,13 @@ def vision_bwd(p: VisionParams, saved, d_out: torch.Tensor, cfg, need: List[bool
             lowest = li if lowest is None else min(lowest, li)
     if lowest is None:
         return [grads[n] for n in names]
+    dx = None if pruned else ops.scatter_rows(dcls, None, B, S, D)
     for i in range(n_layers - 1, max(lowest, 0) - 1, -1):
         lneed = {f: needd[f"layers.{i}.{f}"] for f in LayerParams.FIELDS}
-        dx, gr = layer_bwd(dx, p.layers[i], saved_layers[i], B, S, H, False, lneed)
+        if pruned and i == n_layers - 1:
+            dx, gr = last_layer_bwd_cls(dcls, p.layers[i], saved_layers[i], B, S, H, lneed)
+        else:
+            dx, gr = layer_bwd(dx, p.layers[i], saved_layers[i], B, S, H, False, lneed)
         saved_layers[i] = None
         for f, t in gr.items():
             grads[f"layers.{i}.{f}"] = t

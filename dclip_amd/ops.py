@@ -190,6 +190,33 @@ def attention_bwd(qkv, out, dout, lse, B: int, S: int, H: int, causal: bool):
     return dqkv
 
 
+def attention_cls_fwd(qkv: torch.Tensor, B: int, S: int, H: int):
+    """Attention output of query row 0 of every image only: ([B, H*64], lse [B, H])."""
+    lib = _lib.load()
+    _f32(qkv, "qkv")
+    if qkv.numel() != B * S * 3 * H * 64:
+        raise ValueError("attention_cls_fwd: qkv size")
+    out = torch.empty((B, H * 64), dtype=torch.float32, device=qkv.device)
+    lse = torch.empty((B, H), dtype=torch.float32, device=qkv.device)
+    _lib.check(lib.dclip_attention_cls_fwd(qkv.data_ptr(), out.data_ptr(), lse.data_ptr(), B, S, H, _stream()),
+               "attention_cls_fwd")
+    return out, lse
+
+
+def attention_cls_bwd(qkv, out, dout, lse, B: int, S: int, H: int):
+    lib = _lib.load()
+    _f32(qkv, "qkv"), _f32(out, "out"), _f32(dout, "dout"), _f32(lse, "lse")
+    if qkv.numel() != B * S * 3 * H * 64 or out.numel() != B * H * 64 or dout.numel() != out.numel() \
+            or lse.numel() != B * H:
+        raise ValueError("attention_cls_bwd: shape mismatch")
+    dqkv = torch.empty_like(qkv)
+    _lib.check(lib.dclip_fill(dqkv.data_ptr(), 0.0, dqkv.numel(), _stream()), "fill")
+    delta = torch.empty((B * H,), dtype=torch.float32, device=qkv.device)
+    _lib.check(lib.dclip_attention_cls_bwd(qkv.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(),
+                                           dqkv.data_ptr(), delta.data_ptr(), B, S, H, _stream()), "attention_cls_bwd")
+    return dqkv
+
+
 # ------------------------------------------------------------------------------------------- embeddings
 
 def im2col(pixels: torch.Tensor, patch: int) -> torch.Tensor:

@@ -114,6 +114,13 @@ int dclip_attention_fwd(const float* qkv, float* out, float* lse, int B, int S, 
 int dclip_attention_bwd(const float* qkv, const float* out, const float* dout, const float* lse,
                         float* dqkv, float* delta /* scratch [B*H*S] */, int B, int S, int H, int causal,
                         void* stream);
+/* CLS-only form for the LAST vision layer: the model reads only row 0 of the final hidden state
+ * (hf:modeling_clip.py:650), so that layer's attention output is needed for one query row per (image, head).
+ * out [B, H*64], lse [B, H].  _bwd writes d k / d v for every row and d q for the CLS rows of dqkv [B*S, 3*H*64];
+ * the caller zero-fills dqkv first (d q of the other rows is exactly zero).  delta: scratch [B*H]. */
+int dclip_attention_cls_fwd(const float* qkv, float* out, float* lse, int B, int S, int H, void* stream);
+int dclip_attention_cls_bwd(const float* qkv, const float* out, const float* dout, const float* lse, float* dqkv,
+                            float* delta, int B, int S, int H, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Embedding plumbing.
