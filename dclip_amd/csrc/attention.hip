@@ -121,6 +121,8 @@ struct AttnArgs {
   const float* v;
   int ldq, ldkv;
   int Sq, Sk, H;
+  const int32_t* q_rows;  // forward only, optional: ONE query row per batch at sequence position q_rows[b], attending
+                          // keys <= q_rows[b] (the text tower's first-EOS row under the causal mask); then Sq == 1
 };
 
 template <bool CAUSAL>
@@ -137,7 +139,8 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(AttnArgs a, float* __rest
   const int bh = blockIdx.x, b = bh / H, h = bh % H;
   const int q0 = blockIdx.y * TS;
   const int D = H * HD;
-  const float* qbase = a.q + (size_t)b * Sq * a.ldq + h * HD;
+  const int qpos = a.q_rows ? a.q_rows[b] : -1;          // >= 0: single query row at this sequence position
+  const float* qbase = a.q + ((size_t)b * (qpos >= 0 ? S : Sq) + (qpos >= 0 ? qpos : 0)) * a.ldq + h * HD;
   const float* kbase = a.k + (size_t)b * S * a.ldkv + h * HD;
   const float* vbase = a.v + (size_t)b * S * a.ldkv + h * HD;
 
@@ -159,6 +162,7 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(AttnArgs a, float* __rest
   }
   int nkt = (S + TS - 1) / TS;
   if (CAUSAL) nkt = min(nkt, (int)blockIdx.y + 1);
+  if (qpos >= 0) nkt = min(nkt, qpos / TS + 1);
   for (int kt = 0; kt < nkt; ++kt) {
     if (kt > 0) {
       __syncthreads();  // everyone is done with the previous K/V tile
@@ -177,7 +181,7 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(AttnArgs a, float* __rest
       for (int r = 0; r < 4; ++r) {
         const int qrow = q0 + 16 * wave + 4 * qd + r;
         float v = s[nt][r] * kScale;
-        if (key >= S || (CAUSAL && key > qrow)) v = -INFINITY;
+        if (key >= S || (CAUSAL && key > qrow) || (qpos >= 0 && key > qpos)) v = -INFINITY;
         s[nt][r] = v;
         mx[r] = fmaxf(mx[r], v);
       }
@@ -532,7 +536,7 @@ DCLIP_API int dclip_attention_fwd(const float* qkv, float* out, float* lse, int 
   DCLIP_REQUIRE(qkv && out && lse, "attention_fwd: null pointer");
   DCLIP_REQUIRE(B > 0 && S > 0 && H > 0, "attention_fwd: bad shape B=%d S=%d H=%d", B, S, H);
   const int D = H * HD;
-  AttnArgs a{qkv, qkv + D, qkv + 2 * D, 3 * D, 3 * D, S, S, H};
+  AttnArgs a{qkv, qkv + D, qkv + 2 * D, 3 * D, 3 * D, S, S, H, nullptr};
   return launch_fwd(a, out, lse, B, causal, (hipStream_t)stream);
 }
 
@@ -541,7 +545,7 @@ DCLIP_API int dclip_attention_bwd(const float* qkv, const float* out, const floa
   DCLIP_REQUIRE(qkv && out && dout && lse && dqkv && delta, "attention_bwd: null pointer");
   DCLIP_REQUIRE(B > 0 && S > 0 && H > 0, "attention_bwd: bad shape B=%d S=%d H=%d", B, S, H);
   const int D = H * HD;
-  AttnArgs a{qkv, qkv + D, qkv + 2 * D, 3 * D, 3 * D, S, S, H};
+  AttnArgs a{qkv, qkv + D, qkv + 2 * D, 3 * D, 3 * D, S, S, H, nullptr};
   return launch_bwd(a, out, dout, lse, dqkv, 3 * D, dqkv + D, dqkv + 2 * D, 3 * D, delta, B, causal, (hipStream_t)stream);
 }
 
@@ -552,7 +556,7 @@ DCLIP_API int dclip_attention_cls_fwd(const float* qkv, float* out, float* lse, 
   DCLIP_REQUIRE(qkv && out && lse, "attention_cls_fwd: null pointer");
   DCLIP_REQUIRE(B > 0 && S > 0 && H > 0, "attention_cls_fwd: bad shape");
   const int D = H * HD;
-  AttnArgs a{qkv, qkv + D, qkv + 2 * D, S * 3 * D, 3 * D, 1, S, H};
+  AttnArgs a{qkv, qkv + D, qkv + 2 * D, S * 3 * D, 3 * D, 1, S, H, nullptr};
   return launch_fwd(a, out, lse, B, 0, (hipStream_t)stream);
 }
 
@@ -562,8 +566,19 @@ DCLIP_API int dclip_attention_cls_bwd(const float* qkv, const float* out, const 
   DCLIP_REQUIRE(qkv && out && dout && lse && dqkv && delta, "attention_cls_bwd: null pointer");
   DCLIP_REQUIRE(B > 0 && S > 0 && H > 0, "attention_cls_bwd: bad shape");
   const int D = H * HD;
-  AttnArgs a{qkv, qkv + D, qkv + 2 * D, S * 3 * D, 3 * D, 1, S, H};
+  AttnArgs a{qkv, qkv + D, qkv + 2 * D, S * 3 * D, 3 * D, 1, S, H, nullptr};
   return launch_bwd(a, out, dout, lse, dqkv, S * 3 * D, dqkv + D, dqkv + 2 * D, 3 * D, delta, B, 0, (hipStream_t)stream);
+}
+
+// Text tower, last layer, frozen: only the first-EOS row of each caption is pooled (hf:modeling_clip.py:574-581), so
+// the attention output is needed for that one row, against keys 0..eos[b] (causal).  out [B, H*64].
+DCLIP_API int dclip_attention_row_fwd(const float* qkv, const int32_t* rows, float* out, float* lse, int B, int S, int H,
+                                      void* stream) {
+  DCLIP_REQUIRE(qkv && rows && out && lse, "attention_row_fwd: null pointer");
+  DCLIP_REQUIRE(B > 0 && S > 0 && H > 0, "attention_row_fwd: bad shape");
+  const int D = H * HD;
+  AttnArgs a{qkv, qkv + D, qkv + 2 * D, 3 * D, 3 * D, 1, S, H, rows};
+  return launch_fwd(a, out, lse, B, 0, (hipStream_t)stream);
 }
 
 DCLIP_API int dclip_cross_attention_fwd(const float* q, const float* kv, float* out, float* lse, int B, int Lq, int Lk,
@@ -571,7 +586,7 @@ DCLIP_API int dclip_cross_attention_fwd(const float* q, const float* kv, float* 
   DCLIP_REQUIRE(q && kv && out && lse, "cross_attention_fwd: null pointer");
   DCLIP_REQUIRE(B > 0 && Lq > 0 && Lk > 0 && H > 0, "cross_attention_fwd: bad shape B=%d Lq=%d Lk=%d H=%d", B, Lq, Lk, H);
   const int E = H * HD;
-  AttnArgs a{q, kv, kv + E, E, 2 * E, Lq, Lk, H};
+  AttnArgs a{q, kv, kv + E, E, 2 * E, Lq, Lk, H, nullptr};
   return launch_fwd(a, out, lse, B, 0, (hipStream_t)stream);
 }
 
@@ -581,6 +596,6 @@ DCLIP_API int dclip_cross_attention_bwd(const float* q, const float* kv, const f
   DCLIP_REQUIRE(q && kv && out && dout && lse && dq && dkv && delta, "cross_attention_bwd: null pointer");
   DCLIP_REQUIRE(B > 0 && Lq > 0 && Lk > 0 && H > 0, "cross_attention_bwd: bad shape");
   const int E = H * HD;
-  AttnArgs a{q, kv, kv + E, E, 2 * E, Lq, Lk, H};
+  AttnArgs a{q, kv, kv + E, E, 2 * E, Lq, Lk, H, nullptr};
   return launch_bwd(a, out, dout, lse, dq, E, dkv, dkv + E, 2 * E, delta, B, 0, (hipStream_t)stream);
 }

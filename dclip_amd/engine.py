@@ -327,6 +327,29 @@ def text_encoder_fwd(p: TextParams, input_ids: torch.Tensor, cfg, save: bool, hi
     return x, saved_layers
 
 
+def text_fwd_frozen(p: TextParams, input_ids: torch.Tensor, cfg):
+    """get_text_features without gradients: like text_fwd, but the LAST layer is evaluated only where it is read —
+    everything after its attention on the B first-EOS rows, its attention for that one query row per caption
+    (keys 0..eos, causal).  Exact; 9/12 of that layer's GEMM work is never launched."""
+    t = cfg
+    B, T = input_ids.shape
+    D, H = t.hidden_size, t.num_attention_heads
+    eos = ops.first_eos(input_ids, t.eos_token_id)
+    x = ops.text_embed_fwd(input_ids, p.tok, p.pos)
+    for lp in p.layers[:-1]:
+        x, _ = layer_fwd(x, lp, B, T, H, True, t.layer_norm_eps, False)
+    lp = p.layers[-1]
+    ln1, _, _ = ops.layernorm_fwd(x, lp.ln1_w, lp.ln1_b, t.layer_norm_eps, save_stats=False)
+    qkv = ops.gemm(ln1, lp.qkv_w, ops.LAYOUT_NT, bias=lp.qkv_b)
+    attn = ops.attention_row_fwd(qkv, eos, B, T, H)
+    x1 = ops.gemm(attn, lp.out_w, ops.LAYOUT_NT, bias=lp.out_b, residual=ops.gather_rows(x, eos, B, T, D))
+    ln2, _, _ = ops.layernorm_fwd(x1, lp.ln2_w, lp.ln2_b, t.layer_norm_eps, save_stats=False)
+    g = ops.gemm(ln2, lp.fc1_w, ops.LAYOUT_NT, bias=lp.fc1_b, epilogue=ops.EPI_GELU)
+    rows = ops.gemm(g, lp.fc2_w, ops.LAYOUT_NT, bias=lp.fc2_b, residual=x1)
+    pooled, _, _ = ops.layernorm_fwd(rows, p.final_w, p.final_b, t.layer_norm_eps, save_stats=False)
+    return ops.gemm(pooled, p.proj_w, ops.LAYOUT_NT)
+
+
 def text_fwd(p: TextParams, input_ids: torch.Tensor, cfg, save: bool, hidden_out: Optional[list] = None):
     """get_text_features: ids [B,T] -> [B,P]  (hf:modeling_clip.py:541-586, :705-713).  LayerNorm is row-wise, so
     the first-EOS rows are gathered BEFORE final_layer_norm: only B rows are normalised and projected."""

@@ -37,6 +37,9 @@ class TextTowerFn(torch.autograd.Function):
     def forward(ctx, input_ids, cfg, n_layers, *params):
         p = engine.TextParams.from_tensors([_c(t.detach()) for t in params], n_layers)
         save = any(ctx.needs_input_grad[3:])
+        if not save and len(p.layers) > 0:
+            ctx.saved = None
+            return engine.text_fwd_frozen(p, _c(input_ids), cfg)
         out, saved = engine.text_fwd(p, _c(input_ids), cfg, save)
         ctx.p, ctx.saved, ctx.cfg = p, saved, cfg
         return out

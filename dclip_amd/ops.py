@@ -203,6 +203,19 @@ def attention_cls_fwd(qkv: torch.Tensor, B: int, S: int, H: int):
     return out, lse
 
 
+def attention_row_fwd(qkv: torch.Tensor, rows: torch.Tensor, B: int, S: int, H: int):
+    """Causal attention output of ONE row per batch (sequence position rows[b]): [B, H*64]."""
+    lib = _lib.load()
+    _f32(qkv, "qkv"), _idx(rows, B)
+    if qkv.numel() != B * S * 3 * H * 64:
+        raise ValueError("attention_row_fwd: qkv size")
+    out = torch.empty((B, H * 64), dtype=torch.float32, device=qkv.device)
+    lse = torch.empty((B, H), dtype=torch.float32, device=qkv.device)
+    _lib.check(lib.dclip_attention_row_fwd(qkv.data_ptr(), rows.data_ptr(), out.data_ptr(), lse.data_ptr(), B, S, H,
+                                           _stream()), "attention_row_fwd")
+    return out
+
+
 def attention_cls_bwd(qkv, out, dout, lse, B: int, S: int, H: int):
     lib = _lib.load()
     _f32(qkv, "qkv"), _f32(out, "out"), _f32(dout, "dout"), _f32(lse, "lse")

@@ -119,6 +119,10 @@ int dclip_attention_bwd(const float* qkv, const float* out, const float* dout, c
  * out [B, H*64], lse [B, H].  _bwd writes d k / d v for every row and d q for the CLS rows of dqkv [B*S, 3*H*64];
  * the caller zero-fills dqkv first (d q of the other rows is exactly zero).  delta: scratch [B*H]. */
 int dclip_attention_cls_fwd(const float* qkv, float* out, float* lse, int B, int S, int H, void* stream);
+/* Same idea for the frozen text tower's last layer: one query row per caption at position rows[b] (its first EOS,
+ * hf:modeling_clip.py:574-581) against keys 0..rows[b] (causal).  Forward only.  out [B, H*64], lse [B, H]. */
+int dclip_attention_row_fwd(const float* qkv, const int32_t* rows, float* out, float* lse, int B, int S, int H,
+                            void* stream);
 int dclip_attention_cls_bwd(const float* qkv, const float* out, const float* dout, const float* lse, float* dqkv,
                             float* delta, int B, int S, int H, void* stream);
 
