@@ -386,6 +386,62 @@ __global__ void __launch_bounds__(256, 2) gemm_f32_kernel(GemmParams p) {
   // All side inputs of a 32x32 tile (residual / aux / old C) are loaded back to back from clamped addresses before
   // any of them is used, so their latency is paid once per tile instead of once per element.
   const int epi = p.slab ? 0 : p.epilogue;
+  if (m0 + BM <= p.M && n0 + BN <= p.N) {
+    // Interior tile: transpose the accumulators through LDS (the staging buffers are dead: the K loop ended on a
+    // barrier) so that every lane moves 16 bytes and a wave-instruction covers whole 512-byte output rows — 4x fewer
+    // store (and side-input load) instructions than the register-direct layout, all fully coalesced.
+    static_assert(BM * BN <= 2 * (BM + BN) * BK, "C tile must fit in the staging LDS");
+    float* ct = lds;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          ct[(wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * BN + wn * TN + j * 32 + l31] = acc[i][j][r];
+    __syncthreads();
+    constexpr int CHUNKS = BM * BN / 4 / 256;
+    const float* s0 = (epi & DCLIP_EPI_DGELU) ? p.aux : p.residual;
+    const bool has_s0 = epi & (DCLIP_EPI_RESIDUAL | DCLIP_EPI_DGELU);
+    f32x4 side[CHUNKS];
+    if (has_s0) {
+#pragma unroll
+      for (int q = 0; q < CHUNKS; ++q) {
+        const int id = tid + q * 256;
+        const int row = m0 + id / (BN / 4), col = n0 + (id % (BN / 4)) * 4;
+        side[q] = *reinterpret_cast<const f32x4*>(s0 + (size_t)row * p.ldc + col);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < CHUNKS; ++q) {
+      const int id = tid + q * 256;
+      const int lr = id / (BN / 4), lc = (id % (BN / 4)) * 4;
+      const int row = m0 + lr, col = n0 + lc;
+      f32x4 v = *reinterpret_cast<const f32x4*>(ct + lr * BN + lc);
+      if (p.slab) {
+        *reinterpret_cast<f32x4*>(p.slab + ((size_t)blockIdx.y * p.M + row) * p.N + col) = v;
+        continue;
+      }
+      const size_t off = (size_t)row * p.ldc + col;
+      v = v * p.alpha;
+      if (epi & DCLIP_EPI_BIAS) v += *reinterpret_cast<const f32x4*>(p.bias + col);
+      if (epi & DCLIP_EPI_GELU) {
+        if (p.aux) *reinterpret_cast<f32x4*>(p.aux + off) = v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = quick_gelu_f(v[e]);
+      }
+      if (epi & DCLIP_EPI_DGELU) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] *= quick_gelu_grad_f(side[q][e]);
+        if (epi & DCLIP_EPI_RESIDUAL) v += *reinterpret_cast<const f32x4*>(p.residual + off);
+      } else if (epi & DCLIP_EPI_RESIDUAL) {
+        v += side[q];
+      }
+      if (epi & DCLIP_EPI_ACCUM) v += *reinterpret_cast<const f32x4*>(p.C + off);
+      *reinterpret_cast<f32x4*>(p.C + off) = v;
+    }
+    return;
+  }
   const bool has_side0 = epi & (DCLIP_EPI_RESIDUAL | DCLIP_EPI_DGELU);
   const bool has_side1 = epi & DCLIP_EPI_ACCUM;
   float side0[MT][NT][16], side1[MT][NT][16], bcol[NT];
