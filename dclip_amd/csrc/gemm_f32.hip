@@ -535,9 +535,11 @@ struct Plan {
   int bm, bn, splits, k_per_split;
 };
 
-// Tile / split-K choice.  f32 MFMA is slow enough (64 cycles per 32x32x2) that even a 64x64 block tile is
-// compute-bound, so the choice is about filling 256 CUs x 2 resident workgroups with few idle tails.
-Plan make_plan(int M, int N, int K, int split_k) {
+// Tile / split-K choice from a small calibrated cost model (MI355X, tools/gemm_tune.py):
+//   a CU retires its work items back to back at the MFMA rate whatever the number of co-resident workgroups, so
+//   time ~ ceil(items / 256) * (k_tiles * cycles_per_ktile(tile) * eff + fixed(tile)) + slab traffic of a split-K.
+// Smaller tiles balance better and have a cheaper prologue/epilogue, larger ones spend fewer LDS reads per MFMA.
+Plan make_plan(int M, int N, int K, int layout, int split_k) {
   const int cand[4][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}};
   if (const char* force = getenv("DCLIP_GEMM_TILE")) {  // tuning aid: "BMxBN[xSPLITS]"
     int bm = 0, bn = 0, sp = 1;
@@ -547,26 +549,23 @@ Plan make_plan(int M, int N, int K, int split_k) {
       return Plan{bm, bn, cdiv(K, kps), kps};
     }
   }
+  const double mn_major_penalty = (layout & DCLIP_A_KMAJOR ? 0.0 : 0.03) + (layout & DCLIP_B_KMAJOR ? 0.0 : 0.03);
   double best = 1e300;
   Plan pl{128, 128, 1, K};
   for (auto& c : cand) {
     const int bm = c[0], bn = c[1];
     const long tiles = (long)cdiv(M, bm) * cdiv(N, bn);
-    int smax = split_k > 0 ? split_k : 32;
-    for (int s = (split_k > 0 ? split_k : 1); s <= smax; s *= 2) {
-      int kps = cdiv(cdiv(K, s), BK) * BK;
-      int s_eff = cdiv(K, kps);
-      if (split_k <= 0 && s > 1 && kps < 256) break;
-      const long wgs = tiles * s_eff;
-      // two workgroups share a CU's matrix pipes: time ~ ceil(wgs / 512) rounds of 2 tiles per CU
-      const double slots = 2.0 * NUM_CU;
-      const double rounds = (double)((wgs + (long)slots - 1) / (long)slots);
-      // per-workgroup cost ~ MFMA cycles + fixed prologue/epilogue overhead (in units of k-steps)
-      const double per = (double)bm * bn * ((double)kps + 96.0);
-      // small tiles re-read operands more: mild penalty
-      const double eff = (bm == 128 && bn == 128) ? 1.0 : (bm == 64 && bn == 64 ? 1.10 : 1.05);
-      double cost = rounds * per * eff;
-      if (s_eff > 1) cost += 3.0 * (double)M * N * s_eff / 32.0;  // slab write + reduce traffic
+    const double cyc = (bm / 32) * (bn / 32) * 256.0;                       // MFMA cycles per K-tile of this tile
+    const double eff = (bm * bn == 16384 ? 1.05 : (bm * bn == 8192 ? 1.06 : 1.10)) + mn_major_penalty;
+    const double fixed = bm * bn == 16384 ? 12000.0 : (bm * bn == 8192 ? 7000.0 : 4000.0);
+    const int smax = split_k > 0 ? split_k : 32;
+    for (int sp = (split_k > 0 ? split_k : 1); sp <= smax; sp *= 2) {
+      const int kps = cdiv(cdiv(K, sp), BK) * BK;
+      const int s_eff = cdiv(K, kps);
+      if (split_k <= 0 && sp > 1 && kps < 512) break;
+      const long items = tiles * s_eff;
+      double cost = (double)cdiv((int)items, NUM_CU) * ((kps / BK) * cyc * eff + fixed);
+      if (s_eff > 1) cost += 8.0 * s_eff * (double)M * N / 1670.0 + 4000.0;  // slab write + read at ~4 TB/s, + a launch
       if (cost < best) {
         best = cost;
         pl = Plan{bm, bn, s_eff, kps};
@@ -580,8 +579,7 @@ Plan make_plan(int M, int N, int K, int split_k) {
 }  // namespace
 
 DCLIP_API size_t dclip_gemm_f32_workspace(int M, int N, int K, int layout, int split_k) {
-  (void)layout;
-  Plan pl = make_plan(M, N, K, split_k);
+  Plan pl = make_plan(M, N, K, layout, split_k);
   return pl.splits > 1 ? (size_t)pl.splits * M * N * sizeof(float) : 0;
 }
 
@@ -602,7 +600,7 @@ DCLIP_API int dclip_gemm_f32(const float* A, const float* B, float* C, const flo
   DCLIP_REQUIRE(!(epilogue & DCLIP_EPI_RESIDUAL) || residual, "gemm_f32: RESIDUAL without residual");
   DCLIP_REQUIRE(!(epilogue & DCLIP_EPI_DGELU) || aux, "gemm_f32: DGELU without aux");
 
-  Plan pl = make_plan(M, N, K, split_k);
+  Plan pl = make_plan(M, N, K, layout, split_k);
   GemmParams p{A, B, C, bias, residual, aux, M, N, K, lda, ldb, ldc, epilogue, alpha,
                cdiv(M, pl.bm), cdiv(N, pl.bn), pl.k_per_split, nullptr,
                MODE_GEMM, nullptr, nullptr, nullptr, nullptr, 0, nullptr};
