@@ -165,6 +165,9 @@ def main():
     trainable = [p for p in module.parameters() if p.requires_grad]
     opt = None if args.no_optimizer else optim.FusedAdamW(trainable, lr=hp.learning_rate, max_grad_norm=0.5)
     sync = ddist.GradSync(trainable, group) if world > 1 else None
+    if sync is not None:            # gradient all-reduce overlapped with the backward pass
+        from dclip_amd import functional
+        functional.set_grad_ready_hook(sync.on_grads_ready)
 
     B, T = args.batch, cfg.text.max_position_embeddings
     batch = {                                                     # resident in HBM before the timed region
@@ -181,7 +184,7 @@ def main():
         loss = module.training_step(batch)      # N > 1: this rank's share of the global loss (dist.py)
         loss.backward()
         if sync is not None:
-            sync.reduce()
+            sync.finish()
         if opt is not None:
             opt.step()
             opt.zero_grad(set_to_none=True)

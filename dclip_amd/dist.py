@@ -6,8 +6,8 @@ there; the contract is only that the N-rank loss/gradients equal the single-proc
 batch (fixture F5):
   C1  global negatives: all-gather of the normalised embeddings + of two LSE vectors, inside
       functional.ContrastiveLossFn (forward only — its backward needs no collective).
-  C2  gradient all-reduce of the trainable parameters, bucketed, launched asynchronously so RCCL's
-      kernels overlap whatever backward work is still queued.
+  C2  gradient all-reduce of the trainable parameters, bucketed, launched from INSIDE the hand-written backward
+      (grad-ready hook, one bucket per ViT layer) so RCCL's transfers overlap the layers still to be back-propagated.
 
 Loss scaling: ContrastiveLossFn returns each rank's SHARE of the global loss (sum over ranks = the
 single-process value), so its gradients must be SUMMED over ranks; the per-sample cosine losses are means
@@ -53,50 +53,72 @@ def global_loss_value(loss_image, loss_text, loss_contrastive_share, group) -> t
 
 
 class GradSync:
-    """Bucketed SUM all-reduce of `.grad` over the data-parallel group.
+    """Bucketed SUM all-reduce of the trainable parameters' gradients over the data-parallel group, overlapped with
+    the backward pass.
 
-    Buckets are flat fp32 buffers of ~`bucket_mb` filled in REVERSE parameter order (the order backward produces
-    gradients), reduced with async_op so that, on RCCL, every bucket's collective is in flight while the host is
-    still packing the next; `finish()` waits and scatters the results back into `.grad`.  At ViT-B/32 the
-    trainable set is ~88 M fp32 values = 351 MB: 14 buckets of 25 MB."""
+    `on_grads_ready` is installed as functional's grad-ready hook: the vision tower's backward hands over each
+    layer's gradients the moment they are final (top layer first).  They are packed into a flat fp32 bucket
+    (~`bucket_mb`, one ViT-B layer = 28 MB) and the bucket's all-reduce is launched with async_op — RCCL runs it on
+    its own stream over xGMI while the compute stream keeps back-propagating the layers below.  `finish()` (after
+    `loss.backward()`) reduces whatever the hook never saw (parameters outside the hooked tower), waits for every
+    bucket and writes the reduced values into `param.grad`.  Without the hook installed, `reduce()` = finish()
+    does everything after the backward (still bucketed and asynchronous among buckets)."""
 
     def __init__(self, params: Iterable[torch.nn.Parameter], group, bucket_mb: float = 25.0):
         self.group = group
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
-        self.bucket_elems = int(bucket_mb * (1 << 20) / 4)
-        self._plan = None
-        self._flat = None
+        self._ids = {id(p) for p in self.params}
+        self.bucket_elems = max(1, int(bucket_mb * (1 << 20) / 4))
+        self._pending = []          # (param, grad) waiting for a bucket
+        self._pending_elems = 0
+        self._inflight = []         # (work, flat, [(param, offset, numel)])
+        self._seen = set()
 
-    def _build(self):
-        plan, cur, n = [], [], 0
-        for p in reversed(self.params):
-            if p.grad is None:
-                continue
-            cur.append(p)
-            n += p.numel()
-            if n >= self.bucket_elems:
-                plan.append(cur)
-                cur, n = [], 0
-        if cur:
-            plan.append(cur)
-        self._plan = plan
-        self._flat = [torch.empty(sum(p.numel() for p in b), dtype=torch.float32, device=b[0].device) for b in plan]
-
-    def reduce(self):
+    # ---- called during backward
+    def on_grads_ready(self, pairs):
         if self.group is None:
             return
-        if self._plan is None:
-            self._build()
-        works = []
-        for bucket, flat in zip(self._plan, self._flat):
-            o = 0
-            for p in bucket:
-                flat[o:o + p.numel()].copy_(p.grad.reshape(-1))
-                o += p.numel()
-            works.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
-        for w, bucket, flat in zip(works, self._plan, self._flat):
-            w.wait()
-            o = 0
-            for p in bucket:
-                p.grad.copy_(flat[o:o + p.numel()].view_as(p.grad))
-                o += p.numel()
+        for p, g in pairs:
+            if g is None or id(p) not in self._ids or id(p) in self._seen:
+                continue
+            self._seen.add(id(p))
+            self._pending.append((p, g))
+            self._pending_elems += g.numel()
+        if self._pending_elems >= self.bucket_elems:
+            self._launch()
+
+    def _launch(self):
+        if not self._pending:
+            return
+        dev = self._pending[0][1].device
+        flat = torch.empty(self._pending_elems, dtype=torch.float32, device=dev)
+        layout, o = [], 0
+        for p, g in self._pending:
+            n = g.numel()
+            flat[o:o + n].copy_(g.reshape(-1))
+            layout.append((p, o, n))
+            o += n
+        work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self._inflight.append((work, flat, layout))
+        self._pending, self._pending_elems = [], 0
+
+    # ---- called after backward
+    def finish(self):
+        if self.group is None:
+            return
+        for p in reversed(self.params):                 # whatever no hook delivered (other towers, heads)
+            if p.grad is not None and id(p) not in self._seen:
+                self._seen.add(id(p))
+                self._pending.append((p, p.grad))
+                self._pending_elems += p.grad.numel()
+                if self._pending_elems >= self.bucket_elems:
+                    self._launch()
+        self._launch()
+        for work, flat, layout in self._inflight:
+            work.wait()
+            for p, o, n in layout:
+                if p.grad is not None:
+                    p.grad.copy_(flat[o:o + n].view_as(p.grad))
+        self._inflight, self._seen = [], set()
+
+    reduce = finish

@@ -225,8 +225,10 @@ def vision_fwd(p: VisionParams, pixel_values: torch.Tensor, cfg, save: bool, hid
     return out, saved
 
 
-def vision_bwd(p: VisionParams, saved, d_out: torch.Tensor, cfg, need: List[bool]):
-    """Gradients for VisionParams.tensors() order (None where not needed)."""
+def vision_bwd(p: VisionParams, saved, d_out: torch.Tensor, cfg, need: List[bool], on_ready=None):
+    """Gradients for VisionParams.tensors() order (None where not needed).  `on_ready(dict name -> grad)` is called as
+    soon as a group of gradients is final (the tail, then each layer from the top down, then the head): the
+    data-parallel all-reduce of that group starts while the layers below are still being back-propagated."""
     v = cfg
     cols, emb, m0, r0, saved_layers, cls_tok, mp, rp, pooled, pruned = saved
     B = cls_tok.shape[0]
@@ -241,6 +243,8 @@ def vision_bwd(p: VisionParams, saved, d_out: torch.Tensor, cfg, need: List[bool
     dcls, dg, db = ops.layernorm_bwd(dpooled, cls_tok, p.post_w, mp, rp, need_param_grads=want)
     if want:
         grads["post_w"], grads["post_b"] = dg, db
+    if on_ready is not None:
+        on_ready({n: grads[n] for n in VisionParams.TAIL if grads[n] is not None})
     n_layers = len(p.layers)
     # stop as soon as nothing below still needs a gradient (e.g. only visual_projection trainable)
     lowest = None
@@ -260,6 +264,8 @@ def vision_bwd(p: VisionParams, saved, d_out: torch.Tensor, cfg, need: List[bool
         saved_layers[i] = None
         for f, t in gr.items():
             grads[f"layers.{i}.{f}"] = t
+        if on_ready is not None:
+            on_ready({f"layers.{i}.{f}": t for f, t in gr.items()})
     if lowest < 0:
         want = needd["pre_w"] or needd["pre_b"]
         demb, dg, db = ops.layernorm_bwd(dx, emb, p.pre_w, m0, r0, need_param_grads=want)
@@ -274,6 +280,8 @@ def vision_bwd(p: VisionParams, saved, d_out: torch.Tensor, cfg, need: List[bool
         if needd["patch_w"]:
             dpatch = ops.vision_assemble_bwd(demb, B, S, D)
             grads["patch_w"] = ops.gemm(dpatch, cols, ops.LAYOUT_TN).view_as(p.patch_w)
+        if on_ready is not None:
+            on_ready({n: grads[n] for n in VisionParams.HEAD if grads[n] is not None})
     return [grads[n] for n in names]
 
 

@@ -10,6 +10,16 @@ import torch
 from . import engine, ops
 
 
+# Data-parallel hook: called from inside a tower's backward with [(Parameter, gradient), ...] as soon as those gradients
+# are final, so their all-reduce overlaps the rest of the backward (dist.GradSync.on_grads_ready).  None = no hook.
+_GRAD_READY_HOOK = None
+
+
+def set_grad_ready_hook(fn):
+    global _GRAD_READY_HOOK
+    _GRAD_READY_HOOK = fn
+
+
 def _c(t: torch.Tensor) -> torch.Tensor:
     return t if t.is_contiguous() else t.contiguous()
 
@@ -21,13 +31,19 @@ class VisionTowerFn(torch.autograd.Function):
         save = any(ctx.needs_input_grad[3:])
         out, saved = engine.vision_fwd(p, _c(pixel_values.detach()), cfg, save)
         ctx.p, ctx.saved, ctx.cfg = p, saved, cfg
+        ctx.param_refs = params if save else None          # the nn.Parameters, for the data-parallel hook
         return out
 
     @staticmethod
     def backward(ctx, d_out):
         if ctx.saved is None:
             raise RuntimeError("VisionTowerFn.backward called twice, or forward ran without grad")
-        grads = engine.vision_bwd(ctx.p, ctx.saved, _c(d_out), ctx.cfg, list(ctx.needs_input_grad[3:]))
+        on_ready = None
+        if _GRAD_READY_HOOK is not None:
+            by_name = dict(zip(ctx.p.names(), ctx.param_refs))
+            hook = _GRAD_READY_HOOK
+            on_ready = lambda named: hook([(by_name[n], g) for n, g in named.items()])      # noqa: E731
+        grads = engine.vision_bwd(ctx.p, ctx.saved, _c(d_out), ctx.cfg, list(ctx.needs_input_grad[3:]), on_ready)
         ctx.saved = None
         return (None, None, None, *grads)
 

@@ -41,7 +41,7 @@ def _batch(cfg, B):
             "teacher_text_emb": synth.synth_embeddings(B, cfg.projection_dim, seed=5)}
 
 
-def _worker(rank, world, port, B, out):
+def _worker(rank, world, port, B, out, overlap):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from dclip_amd import dist as ddist
@@ -50,10 +50,15 @@ def _worker(rank, world, port, B, out):
     full = _batch(cfg, B)
     Bl = B // world
     shard = {k: v[rank * Bl:(rank + 1) * Bl].contiguous() for k, v in full.items()}
+    from dclip_amd import functional
+    trainable = [p for p in mod.parameters() if p.requires_grad]
+    sync = ddist.GradSync(trainable, dist.group.WORLD, bucket_mb=0.05)
+    if overlap:
+        functional.set_grad_ready_hook(sync.on_grads_ready)      # all-reduce launched from inside the backward
     share = mod.training_step(shard)
     share.backward()
-    trainable = [p for p in mod.parameters() if p.requires_grad]
-    ddist.GradSync(trainable, dist.group.WORLD, bucket_mb=0.05).reduce()
+    sync.finish()
+    functional.set_grad_ready_hook(None)
     tot = share.detach().clone()
     dist.all_reduce(tot)
     torch.cuda.synchronize()
@@ -63,10 +68,11 @@ def _worker(rank, world, port, B, out):
     dist.destroy_process_group()
 
 
-def test_two_ranks_equal_single_process():
+@pytest.mark.parametrize("overlap", [False, True])
+def test_two_ranks_equal_single_process(overlap):
     B, world = 8, 2
     out = mp.Manager().dict()
-    mp.spawn(_worker, args=(world, _free_port(), B, out), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), B, out, overlap), nprocs=world, join=True)
     dev = torch.device("cuda:0")
     cfg, mod = _build(dev, None)
     loss = mod.training_step(_batch(cfg, B))
