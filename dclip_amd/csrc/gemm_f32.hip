@@ -601,6 +601,13 @@ DCLIP_API int dclip_gemm_f32(const float* A, const float* B, float* C, const flo
   DCLIP_REQUIRE(!(epilogue & DCLIP_EPI_DGELU) || aux, "gemm_f32: DGELU without aux");
 
   Plan pl = make_plan(M, N, K, layout, split_k);
+  // buffer descriptors address 2^31-1 bytes from a work item's origin: a [K][M]-major operand spans k_per_split rows
+  DCLIP_REQUIRE(ak || (double)pl.k_per_split * lda * 4.0 < 2147483647.0, "gemm_f32: A slice of %d x %d floats exceeds 2 GiB "
+                "per K split; raise split_k", pl.k_per_split, lda);
+  DCLIP_REQUIRE(bk || (double)pl.k_per_split * ldb * 4.0 < 2147483647.0, "gemm_f32: B slice of %d x %d floats exceeds 2 GiB "
+                "per K split; raise split_k", pl.k_per_split, ldb);
+  DCLIP_REQUIRE((double)128 * (ak ? lda : 1) * 4.0 < 2147483647.0 && (double)128 * (bk ? ldb : 1) * 4.0 < 2147483647.0,
+                "gemm_f32: leading dimension too large");
   GemmParams p{A, B, C, bias, residual, aux, M, N, K, lda, ldb, ldc, epilogue, alpha,
                cdiv(M, pl.bm), cdiv(N, pl.bn), pl.k_per_split, nullptr,
                MODE_GEMM, nullptr, nullptr, nullptr, nullptr, 0, nullptr};
