@@ -60,6 +60,9 @@ SIGNATURES = {
     "dclip_rank_count": (I, [P, P, P, P, P, I, I, I, P, Z, P]),
     "dclip_crop_resize_workspace": (Z, [I, I, I, I]),
     "dclip_crop_resize_u8": (I, [P, P, P, P, I, I, I, I, I, I, I, P, Z, P]),
+    "dclip_gemm_bf16": (I, [P, P, P, P, P, I, I, I, I, I, I, I, I, P]),
+    "dclip_cast_f32_bf16": (I, [P, P, I, I, I, I, P]),
+    "dclip_layernorm_fwd_bf16": (I, [P, P, P, P, I, I, F, P]),
     "dclip_sumsq_blocks": (I, [Z]),
     "dclip_sumsq_f32": (I, [P, Z, P, P]),
     "dclip_clip_coef": (I, [P, I, F, P, P, P]),

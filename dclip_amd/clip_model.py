@@ -166,7 +166,8 @@ class HipCLIPModel(nn.Module):
                                  tm.final_layer_norm.weight, tm.final_layer_norm.bias, self.text_projection.weight)
 
     # ------------------------------------------------------------------ reference call surface
-    def get_image_features(self, pixel_values: torch.Tensor = None, **kwargs) -> torch.Tensor:
+    def get_image_features(self, pixel_values: torch.Tensor = None, precision: str = "fp32", **kwargs) -> torch.Tensor:
+        """precision="bf16" (opt-in, frozen use only): GEMM inputs in bf16 on the bf16 MFMA path, everything else fp32."""
         if pixel_values is None:
             raise ValueError("You have to specify pixel_values")
         v = self.config.vision
@@ -174,7 +175,24 @@ class HipCLIPModel(nn.Module):
             raise ValueError(f"Input image size ({pixel_values.shape[-2]}*{pixel_values.shape[-1]}) doesn't match "
                              f"model ({v.image_size}*{v.image_size}).")          # hf:modeling_clip.py:204-207
         p = self.vision_params()
+        if precision == "bf16":
+            if torch.is_grad_enabled() and any(t.requires_grad for t in p.tensors()):
+                raise RuntimeError("precision='bf16' is a forward-only path for frozen towers: call it under torch.no_grad()")
+            pd = engine.VisionParams.from_tensors([t.detach() for t in p.tensors()], v.num_hidden_layers)
+            return engine.vision_fwd_bf16(pd, pixel_values.float().contiguous(), v, self._bf16_cache())
+        if precision != "fp32":
+            raise ValueError(f"precision {precision!r}")
         return functional.VisionTowerFn.apply(pixel_values.float(), v, v.num_hidden_layers, *p.tensors())
+
+    def _bf16_cache(self) -> dict:
+        """bf16 copies of the GEMM weights, rebuilt whenever any parameter was modified in place (optimizer step,
+        load_state_dict): keyed on the parameters' version counters."""
+        ver = tuple(p._version for p in self.parameters())
+        c = getattr(self, "_bf16_w", None)
+        if c is None or c.get("__ver__") != ver:
+            c = {"__ver__": ver}
+            object.__setattr__(self, "_bf16_w", c)
+        return c
 
     def get_text_features(self, input_ids: torch.Tensor = None, attention_mask=None, **kwargs) -> torch.Tensor:
         """`attention_mask` is accepted and ignored: under the causal mask trailing pads cannot influence the

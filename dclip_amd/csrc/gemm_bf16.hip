@@ -1,0 +1,333 @@
+// bf16-input GEMM on v_mfma_f32_32x32x16_bf16 (fp32 accumulate) for the FROZEN towers of the step — the teacher's
+// region encoder (training/image_tokenizer.py:119-120, 8 crops per image) and, optionally, the frozen text tower —
+// in BASELINE configs c3 / c5 ("bf16 MFMA").  Forward only:  C[M,N] = epilogue( A[M,K] W[N,K]^T ).
+//
+// Same skeleton as gemm_f32.hip (block tile 128x128 or 64x64, 4 waves of 2x2 / 1x1 MFMA tiles, buffer-load staging
+// with a scalar K walk, double-buffered XOR-swizzled LDS, LDS-transposed 16-byte epilogue), with K-tiles of 64 bf16
+// = the same 128-byte rows: a lane (row = lane&31, half = lane>>5) reads 16-byte slot 2s+half and holds
+// k = 16s + 8*half + {0..7}, exactly one MFMA operand per ds_read_b128.  At 16x the fp32 MFMA rate the kernel is
+// bounded by L2 -> LDS traffic (64 KB per 512 MFMA cycles per workgroup), not by the matrix pipes.
+#include "common.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int BKH = 64;  // K-tile in bf16 elements (128 bytes per row)
+
+struct GemmBf16Params {
+  const __bf16* A;
+  const __bf16* W;
+  void* C;
+  const float* bias;
+  const float* residual;
+  int M, N, K;
+  int lda, ldw, ldc;
+  int epilogue;
+  int out_bf16;
+  int tiles_m, tiles_n;
+};
+
+__device__ __forceinline__ unsigned short f32_to_bf16_bits(float x) {
+  __bf16 b = (__bf16)x;  // v_cvt_pk_bf16_f32: round-to-nearest-even, NaN stays NaN
+  return __builtin_bit_cast(unsigned short, b);
+}
+
+__device__ __forceinline__ int xcd_remap16(int bid, int nwg) {
+  int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, i = bid >> 3;
+  int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + i;
+}
+
+template <int BM, int BN>
+__global__ void __launch_bounds__(256, 2) gemm_bf16_kernel(GemmBf16Params p) {
+  constexpr int WM = 2, WN = 2;
+  constexpr int TM = BM / WM, TN = BN / WN;
+  constexpr int MT = TM / 32, NT = TN / 32;
+  constexpr int A_CHUNKS = BM * 8 / 256, B_CHUNKS = BN * 8 / 256;  // 16-byte chunks per thread per K-tile
+  constexpr int ROW = BKH;                                          // bf16 elements per LDS row
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  __bf16* As = reinterpret_cast<__bf16*>(lds_raw);     // [2][BM*64]
+  __bf16* Bs = As + 2 * BM * ROW;                      // [2][BN*64]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int l31 = lane & 31, half = lane >> 5;
+
+  constexpr int GROUP_M = 8;
+  const int nwg = p.tiles_m * p.tiles_n;
+  const int swz = xcd_remap16(blockIdx.x, nwg);
+  const int per_group = GROUP_M * p.tiles_n;
+  const int first_m = (swz / per_group) * GROUP_M;
+  const int gsize = min(GROUP_M, p.tiles_m - first_m);
+  const int tile_m = first_m + (swz % per_group) % gsize, tile_n = (swz % per_group) / gsize;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int nk = (p.K + BKH - 1) / BKH;
+
+  const __bf16* a_org = p.A + (size_t)m0 * p.lda;
+  const __bf16* w_org = p.W + (size_t)n0 * p.ldw;
+  const int a_rows = min(BM, p.M - m0), w_rows = min(BN, p.N - n0);
+  const size_t a_bytes = ((size_t)(a_rows - 1) * p.lda + p.K) * 2, w_bytes = ((size_t)(w_rows - 1) * p.ldw + p.K) * 2;
+  const __amdgpu_buffer_rsrc_t a_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a_org), 0, (int)min(a_bytes, (size_t)0x7fffffff), 0x00020000);
+  const __amdgpu_buffer_rsrc_t w_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(w_org), 0, (int)min(w_bytes, (size_t)0x7fffffff), 0x00020000);
+  int a_voff[A_CHUNKS], w_voff[B_CHUNKS];
+#pragma unroll
+  for (int c = 0; c < A_CHUNKS; ++c) {
+    const int id = tid + c * 256;
+    a_voff[c] = (min(id >> 3, a_rows - 1) * p.lda + (id & 7) * 8) * 2;
+  }
+#pragma unroll
+  for (int c = 0; c < B_CHUNKS; ++c) {
+    const int id = tid + c * 256;
+    w_voff[c] = (min(id >> 3, w_rows - 1) * p.ldw + (id & 7) * 8) * 2;
+  }
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  u32x4 ra[A_CHUNKS], rb[B_CHUNKS];
+
+  auto load_tile = [&](int kt) {
+#pragma unroll
+    for (int c = 0; c < A_CHUNKS; ++c) ra[c] = __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, a_voff[c], kt * (BKH * 2), 0);
+#pragma unroll
+    for (int c = 0; c < B_CHUNKS; ++c) rb[c] = __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, w_voff[c], kt * (BKH * 2), 0);
+  };
+  // `krem` < 64 only in a ragged last tile: zero the elements k >= K (they would read the next row's bytes)
+  auto mask_chunk = [&](u32x4 v, int slot, int krem) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int k = slot * 8 + 2 * e;
+      unsigned int w = v[e];
+      if (k >= krem) w = 0;
+      else if (k + 1 >= krem) w &= 0xffffu;
+      v[e] = w;
+    }
+    return v;
+  };
+  auto store_chunk = [&](int buf, int c, int krem) {
+    if (c < A_CHUNKS) {
+      const int id = tid + c * 256, row = id >> 3, slot = id & 7;
+      u32x4 v = ra[c];
+      if (krem < BKH) v = mask_chunk(v, slot, krem);
+      *reinterpret_cast<u32x4*>(As + buf * BM * ROW + row * ROW + ((slot ^ ((row >> 1) & 7)) << 3)) = v;
+    } else {
+      const int cb = c - A_CHUNKS;
+      const int id = tid + cb * 256, row = id >> 3, slot = id & 7;
+      u32x4 v = rb[cb];
+      if (krem < BKH) v = mask_chunk(v, slot, krem);
+      *reinterpret_cast<u32x4*>(Bs + buf * BN * ROW + row * ROW + ((slot ^ ((row >> 1) & 7)) << 3)) = v;
+    }
+  };
+  auto read_frags = [&](const __bf16* a, const __bf16* b, int s, bf16x8 (&fa)[MT], bf16x8 (&fb)[NT]) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int row = wm * TM + i * 32 + l31;
+      fa[i] = *reinterpret_cast<const bf16x8*>(a + row * ROW + (((2 * s + half) ^ ((row >> 1) & 7)) << 3));
+    }
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int row = wn * TN + j * 32 + l31;
+      fb[j] = *reinterpret_cast<const bf16x8*>(b + row * ROW + (((2 * s + half) ^ ((row >> 1) & 7)) << 3));
+    }
+  };
+  // One K-tile: 4 k-steps of MT*NT MFMAs; with `stage`, the next tile's loads go out first and its LDS writes are
+  // spread behind the MFMA steps (pinned with sched_barrier, as in gemm_f32.hip).
+  auto compute = [&](int buf, int kt, bool stage, int krem_next) {
+    const __bf16* a = As + buf * BM * ROW;
+    const __bf16* b = Bs + buf * BN * ROW;
+    constexpr int NCH = A_CHUNKS + B_CHUNKS;
+    bf16x8 fa[2][MT], fb[2][NT];
+    read_frags(a, b, 0, fa[0], fb[0]);
+    __builtin_amdgcn_sched_barrier(0);
+    if (stage) load_tile(kt + 1);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      if (s + 1 < 4) read_frags(a, b, s + 1, fa[(s + 1) & 1], fb[(s + 1) & 1]);
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s & 1][i], fb[s & 1][j], acc[i][j], 0, 0, 0);
+      if (stage && s >= 1) {  // a third of the chunks goes out behind each of k-steps 1..3
+        const int lo = NCH * (s - 1) / 3, hi = (s == 3) ? NCH : NCH * s / 3;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+          if (c >= lo && c < hi) store_chunk(buf ^ 1, c, krem_next);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  };
+
+  load_tile(0);
+#pragma unroll
+  for (int c = 0; c < A_CHUNKS + B_CHUNKS; ++c) store_chunk(0, c, p.K);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const bool stage = kt + 1 < nk;
+    compute(kt & 1, kt, stage, p.K - (kt + 1) * BKH);
+    __syncthreads();
+  }
+
+  // ---- epilogue: accumulators -> LDS (staging buffers are dead) -> 16-byte rows
+  float* ct = reinterpret_cast<float*>(lds_raw);
+  static_assert(BM * BN * 4 <= 2 * (BM + BN) * ROW * 2, "C tile must fit in the staging LDS");
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        ct[(wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * BN + wn * TN + j * 32 + l31] = acc[i][j][r];
+  __syncthreads();
+  constexpr int CHUNKS = BM * BN / 4 / 256;
+#pragma unroll
+  for (int q = 0; q < CHUNKS; ++q) {
+    const int id = tid + q * 256;
+    const int lr = id / (BN / 4), lc = (id % (BN / 4)) * 4;
+    const int row = m0 + lr, col = n0 + lc;
+    if (row >= p.M || col >= p.N) continue;  // N % 4 == 0: a chunk is inside or outside as a whole
+    f32x4 v = *reinterpret_cast<const f32x4*>(ct + lr * BN + lc);
+    if (p.epilogue & DCLIP_EPI_BIAS) v += *reinterpret_cast<const f32x4*>(p.bias + col);
+    if (p.epilogue & DCLIP_EPI_GELU) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = quick_gelu_f(v[e]);
+    }
+    const size_t off = (size_t)row * p.ldc + col;
+    if (p.epilogue & DCLIP_EPI_RESIDUAL) v += *reinterpret_cast<const f32x4*>(p.residual + off);
+    if (p.out_bf16) {
+      u16x4 o = {f32_to_bf16_bits(v[0]), f32_to_bf16_bits(v[1]), f32_to_bf16_bits(v[2]), f32_to_bf16_bits(v[3])};
+      *reinterpret_cast<u16x4*>(reinterpret_cast<unsigned short*>(p.C) + off) = o;
+    } else {
+      *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + off) = v;
+    }
+  }
+}
+
+// y[i] = bf16(x[i]); rows of `cols` floats written with leading dimension ldy (>= cols, zero padded)
+__global__ void __launch_bounds__(256) cast_bf16_kernel(const float* __restrict__ x, unsigned short* __restrict__ y, int rows,
+                                                        int cols, int ldx, int ldy) {
+  const int ld4 = ldy >> 2;
+  const size_t total = (size_t)rows * ld4;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % ld4) * 4;
+    const size_t r = i / ld4;
+    u16x4 o = {0, 0, 0, 0};
+    if (c + 3 < cols) {
+      f32x4 v = *reinterpret_cast<const f32x4*>(x + r * ldx + c);
+      o = u16x4{f32_to_bf16_bits(v[0]), f32_to_bf16_bits(v[1]), f32_to_bf16_bits(v[2]), f32_to_bf16_bits(v[3])};
+    } else {
+      for (int e = 0; e < 4; ++e)
+        if (c + e < cols) o[e] = f32_to_bf16_bits(x[r * ldx + c + e]);
+    }
+    *reinterpret_cast<u16x4*>(y + r * ldy + c) = o;
+  }
+}
+
+// LayerNorm with bf16 output (fp32 statistics and affine): one wave per row
+template <int NC>
+__global__ void __launch_bounds__(256) ln_fwd_bf16_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, unsigned short* __restrict__ y,
+                                                          int rows, int D, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int d4 = D >> 2;
+  const f32x4* xr = reinterpret_cast<const f32x4*>(x + (size_t)row * D);
+  f32x4 v[NC];
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    int i = lane + 64 * c;
+    v[c] = (i < d4) ? xr[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+    s += (v[c][0] + v[c][1]) + (v[c][2] + v[c][3]);
+  }
+  const float mu = wave_sum(s) / (float)D;
+  float q = 0.f;
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    int i = lane + 64 * c;
+    if (i < d4) {
+      f32x4 d = v[c] - mu;
+      q += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+    }
+  }
+  const float rs = rsqrtf(wave_sum(q) / (float)D + eps);
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    int i = lane + 64 * c;
+    if (i < d4) {
+      f32x4 o = (v[c] - mu) * rs * reinterpret_cast<const f32x4*>(gamma)[i] + reinterpret_cast<const f32x4*>(beta)[i];
+      u16x4 b = {f32_to_bf16_bits(o[0]), f32_to_bf16_bits(o[1]), f32_to_bf16_bits(o[2]), f32_to_bf16_bits(o[3])};
+      *reinterpret_cast<u16x4*>(y + (size_t)row * D + i * 4) = b;
+    }
+  }
+}
+
+inline int grid_for(size_t work) {
+  size_t b = (work + 255) / 256;
+  return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
+}
+
+}  // namespace
+
+DCLIP_API int dclip_gemm_bf16(const void* A, const void* W, void* C, const float* bias, const float* residual, int M, int N,
+                              int K, int lda, int ldw, int ldc, int epilogue, int out_bf16, void* stream) {
+  DCLIP_REQUIRE(A && W && C, "gemm_bf16: null operand");
+  DCLIP_REQUIRE(M > 0 && N > 0 && K > 0, "gemm_bf16: bad shape M=%d N=%d K=%d", M, N, K);
+  DCLIP_REQUIRE(lda % 8 == 0 && ldw % 8 == 0 && lda >= K && ldw >= K, "gemm_bf16: lda/ldw must be multiples of 8 and >= K");
+  DCLIP_REQUIRE(N % 4 == 0 && ldc % 4 == 0 && ldc >= N, "gemm_bf16: N / ldc must be multiples of 4");
+  DCLIP_REQUIRE(((uintptr_t)A | (uintptr_t)W | (uintptr_t)C) % 16 == 0, "gemm_bf16: operands must be 16-byte aligned");
+  DCLIP_REQUIRE(!(epilogue & ~(DCLIP_EPI_BIAS | DCLIP_EPI_GELU | DCLIP_EPI_RESIDUAL)), "gemm_bf16: unsupported epilogue bits");
+  DCLIP_REQUIRE(!(epilogue & DCLIP_EPI_BIAS) || bias, "gemm_bf16: BIAS without bias");
+  DCLIP_REQUIRE(!(epilogue & DCLIP_EPI_RESIDUAL) || (residual && !out_bf16), "gemm_bf16: RESIDUAL needs an fp32 output");
+  const bool small = (long)cdiv(M, 128) * cdiv(N, 128) < 256;  // fewer tiles than CUs: use the finer tile
+  const int bm = small ? 64 : 128, bn = bm;
+  GemmBf16Params p{(const __bf16*)A, (const __bf16*)W, C, bias, residual, M, N, K, lda, ldw, ldc, epilogue, out_bf16,
+                   cdiv(M, bm), cdiv(N, bn)};
+  const size_t lds = (size_t)2 * (bm + bn) * BKH * 2;
+  hipStream_t st = (hipStream_t)stream;
+  if (small) hipLaunchKernelGGL((gemm_bf16_kernel<64, 64>), dim3(p.tiles_m * p.tiles_n), dim3(256), lds, st, p);
+  else hipLaunchKernelGGL((gemm_bf16_kernel<128, 128>), dim3(p.tiles_m * p.tiles_n), dim3(256), lds, st, p);
+  DCLIP_CHECK_LAUNCH("gemm_bf16");
+  return DCLIP_OK;
+}
+
+DCLIP_API int dclip_cast_f32_bf16(const float* x, void* y, int rows, int cols, int ldx, int ldy, void* stream) {
+  DCLIP_REQUIRE(x && y && rows > 0 && cols > 0, "cast_f32_bf16: bad arguments");
+  DCLIP_REQUIRE(ldx >= cols && ldy >= cols && ldy % 4 == 0 && ldx % 4 == 0, "cast_f32_bf16: ldx/ldy must be multiples of 4");
+  DCLIP_REQUIRE((uintptr_t)x % 16 == 0 && (uintptr_t)y % 8 == 0, "cast_f32_bf16: alignment");
+  hipLaunchKernelGGL(cast_bf16_kernel, dim3(grid_for((size_t)rows * (ldy / 4))), dim3(256), 0, (hipStream_t)stream, x,
+                     (unsigned short*)y, rows, cols, ldx, ldy);
+  DCLIP_CHECK_LAUNCH("cast_f32_bf16");
+  return DCLIP_OK;
+}
+
+DCLIP_API int dclip_layernorm_fwd_bf16(const float* x, const float* gamma, const float* beta, void* y, int rows, int D,
+                                       float eps, void* stream) {
+  DCLIP_REQUIRE(x && gamma && beta && y, "layernorm_fwd_bf16: null pointer");
+  DCLIP_REQUIRE(rows > 0 && D > 0 && D % 4 == 0 && D <= 2048, "layernorm_fwd_bf16: bad D=%d", D);
+  dim3 grid(cdiv(rows, 4)), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  const int nc = cdiv(D / 4, 64);
+  unsigned short* yy = (unsigned short*)y;
+#define LN16(NC) hipLaunchKernelGGL((ln_fwd_bf16_kernel<NC>), grid, block, 0, st, x, gamma, beta, yy, rows, D, eps)
+  if (nc <= 1) LN16(1);
+  else if (nc == 2) LN16(2);
+  else if (nc == 3) LN16(3);
+  else if (nc == 4) LN16(4);
+  else LN16(8);
+#undef LN16
+  DCLIP_CHECK_LAUNCH("layernorm_fwd_bf16");
+  return DCLIP_OK;
+}

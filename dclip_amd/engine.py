@@ -285,6 +285,54 @@ def vision_bwd(p: VisionParams, saved, d_out: torch.Tensor, cfg, need: List[bool
     return [grads[n] for n in names]
 
 
+# --------------------------------------------------------------------------------------------- frozen towers in bf16
+# Opt-in mixed precision for towers that never receive gradients (the teacher's region encoder, the frozen text
+# tower; BASELINE configs c3 / c5): GEMM inputs are bf16 (weights converted once, activations converted by the
+# producing kernel), accumulation, residual stream, LayerNorm statistics, softmax and biases stay fp32.
+
+def _w16(cache: dict, key: str, w: torch.Tensor) -> torch.Tensor:
+    t = cache.get(key)
+    if t is None:
+        t = ops.cast_bf16(w.detach().reshape(w.shape[0], -1).contiguous())
+        cache[key] = t
+    return t
+
+
+def _layer_fwd_bf16(x, p: LayerParams, c: dict, pre: str, B: int, S: int, H: int, causal: bool, eps: float):
+    ln1 = ops.layernorm_fwd_bf16(x, p.ln1_w, p.ln1_b, eps)
+    qkv = ops.gemm_bf16(ln1, _w16(c, pre + "qkv", p.qkv_w), bias=p.qkv_b)
+    attn, _ = ops.attention_fwd(qkv, B, S, H, causal)
+    x1 = ops.gemm_bf16(ops.cast_bf16(attn), _w16(c, pre + "out", p.out_w), bias=p.out_b, residual=x)
+    ln2 = ops.layernorm_fwd_bf16(x1, p.ln2_w, p.ln2_b, eps)
+    g = ops.gemm_bf16(ln2, _w16(c, pre + "fc1", p.fc1_w), bias=p.fc1_b, gelu=True, out_bf16=True)
+    return ops.gemm_bf16(g, _w16(c, pre + "fc2", p.fc2_w), bias=p.fc2_b, residual=x1)
+
+
+def vision_fwd_bf16(p: VisionParams, pixel_values: torch.Tensor, cfg, cache: dict) -> torch.Tensor:
+    """Frozen get_image_features with bf16 GEMM inputs; `cache` keeps the converted weights between calls."""
+    v = cfg
+    B = pixel_values.shape[0]
+    S, D, H = v.seq_len, v.hidden_size, v.num_attention_heads
+    cols = ops.cast_bf16(ops.im2col(pixel_values, v.patch_size))
+    patch = ops.gemm_bf16(cols, _w16(cache, "patch", p.patch_w), k=v.patch_dim)
+    x, _, _ = ops.layernorm_fwd(ops.vision_assemble_fwd(patch, p.class_embedding, p.pos, B, S, D), p.pre_w, p.pre_b,
+                                v.layer_norm_eps, save_stats=False)
+    for li, lp in enumerate(p.layers[:-1]):
+        x = _layer_fwd_bf16(x, lp, cache, f"v{li}.", B, S, H, False, v.layer_norm_eps)
+    lp, pre = p.layers[-1], f"v{len(p.layers) - 1}."
+    # last layer on the CLS rows only (see last_layer_fwd_cls)
+    ln1 = ops.layernorm_fwd_bf16(x, lp.ln1_w, lp.ln1_b, v.layer_norm_eps)
+    qkv = ops.gemm_bf16(ln1, _w16(cache, pre + "qkv", lp.qkv_w), bias=lp.qkv_b)
+    attn, _ = ops.attention_cls_fwd(qkv, B, S, H)
+    x1 = ops.gemm_bf16(ops.cast_bf16(attn), _w16(cache, pre + "out", lp.out_w), bias=lp.out_b,
+                       residual=ops.gather_rows(x, None, B, S, D))
+    ln2 = ops.layernorm_fwd_bf16(x1, lp.ln2_w, lp.ln2_b, v.layer_norm_eps)
+    g = ops.gemm_bf16(ln2, _w16(cache, pre + "fc1", lp.fc1_w), bias=lp.fc1_b, gelu=True, out_bf16=True)
+    cls_tok = ops.gemm_bf16(g, _w16(cache, pre + "fc2", lp.fc2_w), bias=lp.fc2_b, residual=x1)
+    pooled, _, _ = ops.layernorm_fwd(cls_tok, p.post_w, p.post_b, v.layer_norm_eps, save_stats=False)
+    return ops.gemm(pooled, p.proj_w, ops.LAYOUT_NT)          # [B,D] x [P,D]: tiny, kept in exact fp32
+
+
 # --------------------------------------------------------------------------------------------- text tower
 
 @dataclass

@@ -517,6 +517,64 @@ def mask_rows(x, count):
     return x
 
 
+# ------------------------------------------------------------------------------------------- bf16 frozen-tower path
+
+def _bf16(t: torch.Tensor, name: str) -> torch.Tensor:
+    if not (t.is_cuda and t.dtype == torch.bfloat16 and t.is_contiguous()):
+        raise ValueError(f"{name}: expected a contiguous bfloat16 CUDA tensor")
+    return t
+
+
+def cast_bf16(x: torch.Tensor, pad_to: int = 8) -> torch.Tensor:
+    """[rows, cols] fp32 -> bf16 with the row length rounded up to `pad_to` (zero filled)."""
+    lib = _lib.load()
+    _f32(x, "x")
+    rows, cols = x.shape
+    ld = (cols + pad_to - 1) // pad_to * pad_to
+    y = torch.empty((rows, ld), dtype=torch.bfloat16, device=x.device)
+    _lib.check(lib.dclip_cast_f32_bf16(x.data_ptr(), y.data_ptr(), rows, cols, cols, ld, _stream()), "cast_f32_bf16")
+    return y
+
+
+def layernorm_fwd_bf16(x, gamma, beta, eps: float) -> torch.Tensor:
+    lib = _lib.load()
+    _f32(x, "x"), _f32(gamma, "gamma"), _f32(beta, "beta")
+    D = x.shape[-1]
+    rows = x.numel() // D
+    y = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    _lib.check(lib.dclip_layernorm_fwd_bf16(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), rows, D,
+                                            float(eps), _stream()), "layernorm_fwd_bf16")
+    return y
+
+
+def gemm_bf16(a: torch.Tensor, w: torch.Tensor, *, n: Optional[int] = None, k: Optional[int] = None,
+              bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None, gelu: bool = False,
+              out_bf16: bool = False) -> torch.Tensor:
+    """y = epilogue(a @ w^T): a [M, lda>=K] and w [N, ldw>=K] bf16 (K-major), fp32 accumulation; y fp32 or bf16."""
+    lib = _lib.load()
+    _bf16(a, "a"), _bf16(w, "w")
+    M, lda = a.shape
+    N, ldw = w.shape
+    K = k if k is not None else min(lda, ldw)
+    if n is not None:
+        N = n
+    epi = 0
+    if bias is not None:
+        epi |= EPI_BIAS
+        if _f32(bias, "bias").numel() != N:
+            raise ValueError("gemm_bf16: bias size")
+    if gelu:
+        epi |= EPI_GELU
+    if residual is not None:
+        epi |= EPI_RESIDUAL
+        if tuple(_f32(residual, "residual").shape) != (M, N):
+            raise ValueError("gemm_bf16: residual shape")
+    out = torch.empty((M, N), dtype=torch.bfloat16 if out_bf16 else torch.float32, device=a.device)
+    _lib.check(lib.dclip_gemm_bf16(a.data_ptr(), w.data_ptr(), out.data_ptr(), _ptr(bias), _ptr(residual), M, N, K, lda,
+                                   ldw, N, epi, int(out_bf16), _stream()), "gemm_bf16")
+    return out
+
+
 # ------------------------------------------------------------------------------------------- crop front end
 
 def crop_resize(images_u8: torch.Tensor, dims: torch.Tensor, boxes: torch.Tensor, size: int,

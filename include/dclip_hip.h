@@ -246,6 +246,23 @@ int dclip_crop_resize_u8(const uint8_t* images, const int32_t* dims, const int32
                          size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * bf16 forward path for FROZEN towers (BASELINE configs c3 / c5, "bf16 MFMA"): the teacher's region encoder
+ * (training/image_tokenizer.py:119-120) and the frozen text tower never need gradients, so their GEMMs may run on
+ * v_mfma_f32_32x32x16_bf16 with fp32 accumulation (16x the fp32 MFMA rate).  The residual stream, LayerNorm
+ * statistics, softmax and every epilogue stay fp32; only GEMM INPUTS are bf16.  Opt-in (precision="bf16"); the
+ * default everywhere, and the benched config c2, is exact fp32.
+ *   gemm_bf16: C[M,N] = epilogue( A[M,K] W[N,K]^T ), A and W bf16 K-major (lda, ldw multiples of 8), C fp32 or bf16;
+ *              epilogue bits BIAS | GELU | RESIDUAL (fp32 residual, fp32 output only).
+ *   cast_f32_bf16: row-wise fp32 -> bf16 (round to nearest even), destination rows zero padded to ldy.
+ *   layernorm_fwd_bf16: nn.LayerNorm with fp32 statistics and a bf16 result (the next GEMM's A operand).
+ */
+int dclip_gemm_bf16(const void* A, const void* W, void* C, const float* bias, const float* residual, int M, int N,
+                    int K, int lda, int ldw, int ldc, int epilogue, int out_bf16, void* stream);
+int dclip_cast_f32_bf16(const float* x, void* y, int rows, int cols, int ldx, int ldy, void* stream);
+int dclip_layernorm_fwd_bf16(const float* x, const float* gamma, const float* beta, void* y, int rows, int D,
+                             float eps, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Optimiser tail (pulled into the timed step).
  * sumsq / clip_coef: global-norm clipping as torch.nn.utils.clip_grad_norm_ does it, which is what Lightning's
  *   Trainer(gradient_clip_val=0.5) applies (training/CLIP_image_distill_training.py:41): each tensor writes

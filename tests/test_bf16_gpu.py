@@ -1,0 +1,64 @@
+"""Opt-in bf16 path for frozen towers: GEMM kernel vs a bf16-rounded fp64 reference, and the tower's measured error."""
+import pytest
+import torch
+
+from dclip_amd import config as dcfg, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def rnd(shape, seed, scale=1.0):
+    return torch.randn(shape, generator=torch.Generator().manual_seed(seed)) * scale
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (400, 768, 768), (257, 132, 588), (2048, 3072, 768), (13, 64, 72),
+                                   (12800, 768, 3072)])
+def test_gemm_bf16_matches_rounded_inputs(M, N, K):
+    from dclip_amd import ops
+    dev = torch.device("cuda:0")
+    a, w, bias = rnd((M, K), 1), rnd((N, K), 2, 0.1), rnd((N,), 3)
+    a16, w16 = ops.cast_bf16(a.to(dev)), ops.cast_bf16(w.to(dev))
+    assert a16.shape[1] % 8 == 0 and torch.equal(a16[:, :K].cpu(), a.to(torch.bfloat16))
+    if a16.shape[1] > K:
+        assert float(a16[:, K:].float().abs().sum()) == 0.0
+    want = a.to(torch.bfloat16).double() @ w.to(torch.bfloat16).double().t() + bias.double()
+    got = ops.gemm_bf16(a16, w16, k=K, bias=bias.to(dev))
+    err = float((got.double().cpu() - want).abs().max() / want.abs().max())
+    assert err < 2e-6 * max(1.0, K ** 0.5), err              # only fp32 accumulation error is left
+    res = rnd((M, N), 4)
+    got2 = ops.gemm_bf16(a16, w16, k=K, bias=bias.to(dev), residual=res.to(dev))
+    assert float((got2.double().cpu() - (want + res.double())).abs().max() / want.abs().max()) < 1e-5
+    g16 = ops.gemm_bf16(a16, w16, k=K, bias=bias.to(dev), gelu=True, out_bf16=True)
+    ref = (want * torch.sigmoid(1.702 * want)).to(torch.bfloat16)
+    assert float((g16.cpu().double() - ref.double()).abs().max() / ref.double().abs().max()) < 1e-2
+
+
+def test_layernorm_bf16_and_cast():
+    from dclip_amd import ops
+    dev = torch.device("cuda:0")
+    x, g, b = rnd((33, 768), 1, 2.0), 1 + rnd((768,), 2, 0.1), rnd((768,), 3, 0.1)
+    y = ops.layernorm_fwd_bf16(x.to(dev), g.to(dev), b.to(dev), 1e-5)
+    want = torch.nn.functional.layer_norm(x.double(), (768,), g.double(), b.double(), 1e-5)
+    assert float((y.cpu().double() - want).abs().max()) < 2e-2
+    assert y.dtype == torch.bfloat16
+
+
+@pytest.mark.parametrize("name,mk", [("tiny", dcfg.tiny), ("ViT-B/32", dcfg.vit_b32)])
+def test_frozen_vision_tower_bf16_error(name, mk):
+    """Measured, reported error of the opt-in bf16 tower against the fp32 tower (same weights, same inputs)."""
+    from dclip_amd.clip_model import from_hf_state_dict
+    dev = torch.device("cuda:0")
+    cfg = mk()
+    m = from_hf_state_dict(cfg, synth.synth_clip_state_dict(cfg, seed=0, gain=3.0), device=dev)
+    pix = synth.synth_regions(4, 1, cfg.vision, seed=2)[:, 0].to(dev)
+    with torch.no_grad():
+        f32 = m.get_image_features(pixel_values=pix)
+        b16 = m.get_image_features(pixel_values=pix, precision="bf16")
+        b16_again = m.get_image_features(pixel_values=pix, precision="bf16")
+    assert torch.equal(b16, b16_again)
+    rel = float((b16 - f32).abs().max() / f32.abs().max())
+    cos = torch.nn.functional.cosine_similarity(b16, f32, dim=1).min()
+    print(f"{name}: bf16 tower max rel err {rel:.2e}, min cosine {float(cos):.6f}")
+    assert rel < 3e-2 and float(cos) > 0.999
+    with pytest.raises(RuntimeError):
+        m.get_image_features(pixel_values=pix, precision="bf16")          # grads enabled + trainable params
