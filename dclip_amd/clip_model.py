@@ -194,9 +194,10 @@ class HipCLIPModel(nn.Module):
             object.__setattr__(self, "_bf16_w", c)
         return c
 
-    def get_text_features(self, input_ids: torch.Tensor = None, attention_mask=None, **kwargs) -> torch.Tensor:
+    def get_text_features(self, input_ids: torch.Tensor = None, attention_mask=None, precision: str = "fp32",
+                          **kwargs) -> torch.Tensor:
         """`attention_mask` is accepted and ignored: under the causal mask trailing pads cannot influence the
-        first-EOS row that is pooled."""
+        first-EOS row that is pooled.  precision="bf16": see get_image_features."""
         if input_ids is None:
             raise ValueError("You have to specify input_ids")
         t = self.config.text
@@ -204,13 +205,26 @@ class HipCLIPModel(nn.Module):
             raise ValueError(f"Sequence length must be less than max_position_embeddings (got `sequence length`: "
                              f"{input_ids.shape[-1]} and max_position_embeddings: {t.max_position_embeddings}")
         p = self.text_params()
+        if precision == "bf16":
+            if torch.is_grad_enabled() and any(x.requires_grad for x in p.tensors()):
+                raise RuntimeError("precision='bf16' is a forward-only path for frozen towers: call it under torch.no_grad()")
+            return engine.text_fwd_frozen_bf16(self.text_params_detached(), input_ids.long().contiguous(), t,
+                                               self._bf16_cache())
+        if precision != "fp32":
+            raise ValueError(f"precision {precision!r}")
         return functional.TextTowerFn.apply(input_ids.long(), t, t.num_hidden_layers, *p.tensors())
 
     @torch.no_grad()
-    def text_token_level(self, input_ids: torch.Tensor):
+    def text_token_level(self, input_ids: torch.Tensor, precision: str = "fp32"):
         """Frozen pass used by the meta-teacher: (sentence [B,P], tokens [B,T,P], first-EOS index [B])."""
         t = self.config.text
-        sent, tokens, eos = engine.text_token_level(self.text_params_detached(), input_ids.long().contiguous(), t)
+        ids = input_ids.long().contiguous()
+        if precision == "bf16":
+            sent, tokens, eos = engine.text_token_level_bf16(self.text_params_detached(), ids, t, self._bf16_cache())
+        elif precision == "fp32":
+            sent, tokens, eos = engine.text_token_level(self.text_params_detached(), ids, t)
+        else:
+            raise ValueError(f"precision {precision!r}")
         return sent, tokens.view(input_ids.shape[0], input_ids.shape[1], -1), eos
 
     def text_params_detached(self) -> engine.TextParams:

@@ -461,6 +461,47 @@ def text_bwd(p: TextParams, saved, d_out: torch.Tensor, cfg, need: List[bool]):
     return [grads[n] for n in names]
 
 
+def _text_stack_bf16(p: TextParams, input_ids: torch.Tensor, cfg, cache: dict, n_layers: int):
+    t = cfg
+    B, T = input_ids.shape
+    x = ops.text_embed_fwd(input_ids, p.tok, p.pos)
+    for li, lp in enumerate(p.layers[:n_layers]):
+        x = _layer_fwd_bf16(x, lp, cache, f"t{li}.", B, T, t.num_attention_heads, True, t.layer_norm_eps)
+    return x
+
+
+def text_fwd_frozen_bf16(p: TextParams, input_ids: torch.Tensor, cfg, cache: dict) -> torch.Tensor:
+    """text_fwd_frozen with bf16 GEMM inputs (see the bf16 note above vision_fwd_bf16)."""
+    t = cfg
+    B, T = input_ids.shape
+    D, H = t.hidden_size, t.num_attention_heads
+    eos = ops.first_eos(input_ids, t.eos_token_id)
+    x = _text_stack_bf16(p, input_ids, cfg, cache, len(p.layers) - 1)
+    lp, pre = p.layers[-1], f"t{len(p.layers) - 1}."
+    ln1 = ops.layernorm_fwd_bf16(x, lp.ln1_w, lp.ln1_b, t.layer_norm_eps)
+    qkv = ops.gemm_bf16(ln1, _w16(cache, pre + "qkv", lp.qkv_w), bias=lp.qkv_b)
+    attn = ops.attention_row_fwd(qkv, eos, B, T, H)
+    x1 = ops.gemm_bf16(ops.cast_bf16(attn), _w16(cache, pre + "out", lp.out_w), bias=lp.out_b,
+                       residual=ops.gather_rows(x, eos, B, T, D))
+    ln2 = ops.layernorm_fwd_bf16(x1, lp.ln2_w, lp.ln2_b, t.layer_norm_eps)
+    g = ops.gemm_bf16(ln2, _w16(cache, pre + "fc1", lp.fc1_w), bias=lp.fc1_b, gelu=True, out_bf16=True)
+    rows = ops.gemm_bf16(g, _w16(cache, pre + "fc2", lp.fc2_w), bias=lp.fc2_b, residual=x1)
+    pooled, _, _ = ops.layernorm_fwd(rows, p.final_w, p.final_b, t.layer_norm_eps, save_stats=False)
+    return ops.gemm(pooled, p.proj_w, ops.LAYOUT_NT)
+
+
+def text_token_level_bf16(p: TextParams, input_ids: torch.Tensor, cfg, cache: dict):
+    """text_token_level with bf16 GEMM inputs; the token projection ([B*T,D] x [P,D]) runs in bf16 too."""
+    t = cfg
+    B, T = input_ids.shape
+    x = _text_stack_bf16(p, input_ids, cfg, cache, len(p.layers))
+    ln = ops.layernorm_fwd_bf16(x, p.final_w, p.final_b, t.layer_norm_eps)
+    tokens = ops.gemm_bf16(ln, _w16(cache, "tproj", p.proj_w))
+    eos = ops.first_eos(input_ids, t.eos_token_id)
+    sentence = ops.gather_rows(tokens, eos, B, T, tokens.shape[1])
+    return sentence, tokens, eos
+
+
 def text_token_level(p: TextParams, input_ids: torch.Tensor, cfg):
     """Frozen teacher text pass giving BOTH outputs of one forward (the reference runs the tower twice per caption,
     training/patch_text_aggregation.py:534 and training/CLIP_image_distillation.py:607):

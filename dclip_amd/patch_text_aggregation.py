@@ -172,10 +172,11 @@ class CLIPTextTokenizer:
     CLIPTokenizer loaded from a LOCAL path, or None when callers pass token ids (synthetic configs).
     The BERT / GloVe word-complexity machinery of the reference (:26-143) is never called on this path."""
 
-    def __init__(self, model: HipCLIPModel, tokenizer=None, max_chunk_size: int = 77):
+    def __init__(self, model: HipCLIPModel, tokenizer=None, max_chunk_size: int = 77, precision: str = "fp32"):
         self.model = model
         self.tokenizer = tokenizer
         self.max_chunk_size = max_chunk_size
+        self.precision = precision          # "bf16": opt-in bf16-input GEMMs for this frozen tower (DESIGN.md §9)
 
     @property
     def device(self):
@@ -194,7 +195,7 @@ class CLIPTextTokenizer:
     @torch.no_grad()
     def token_level_ids(self, input_ids: torch.Tensor):
         """(sentence [B,P], tokens [B,T,P], eos [B]) from one frozen forward."""
-        return self.model.text_token_level(self._ids(input_ids))
+        return self.model.text_token_level(self._ids(input_ids), precision=self.precision)
 
     @torch.no_grad()
     def aggregate_text_ids(self, input_ids: torch.Tensor) -> torch.Tensor:
@@ -218,8 +219,9 @@ class CLIPTextTokenizer:
 class CLIPPatchTokenizer:
     """Frozen teacher region side (training/image_tokenizer.py:19-124) without the detector: boxes are inputs."""
 
-    def __init__(self, clip_model: HipCLIPModel):
+    def __init__(self, clip_model: HipCLIPModel, precision: str = "fp32"):
         self.clip_model = clip_model
+        self.precision = precision
 
     @property
     def device(self):
@@ -275,7 +277,7 @@ class CLIPPatchTokenizer:
     @torch.no_grad()
     def encode_regions(self, regions: torch.Tensor) -> torch.Tensor:
         """[N,3,S,S] in [0,1] -> [N,E] (one batched frozen forward)."""
-        return self.clip_model.get_image_features(pixel_values=regions.to(self.device).float())
+        return self.clip_model.get_image_features(pixel_values=regions.to(self.device).float(), precision=self.precision)
 
     @torch.no_grad()
     def encode_weighted_bounding_boxes(self, image, weighted_boxes, full_resolution=False):
@@ -295,8 +297,12 @@ class CLIPPatchTokenizer:
 class PatchTextAggregation(nn.Module):
     def __init__(self, embed_dim=512, num_heads=8, similarity_threshold=0.85, projection_model_path=None,
                  faiss_index_path=None, embeddings_json_path=None, clip_model: Optional[HipCLIPModel] = None,
-                 tokenizer=None):
+                 tokenizer=None, tower_precision: str = "fp32"):
+        """`tower_precision` ("fp32" default = the reference's arithmetic; "bf16" opt-in) selects how the FROZEN
+        region / text towers multiply; the trainable cross_modal_attention always runs in fp32."""
         super().__init__()
+        if tower_precision not in ("fp32", "bf16"):
+            raise ValueError(f"tower_precision {tower_precision!r}")
         if all([projection_model_path, faiss_index_path, embeddings_json_path]):
             raise NotImplementedError("the KNN + projection tokenizer is outside the distillation step "
                                       "(README.md:21: leave these paths blank)")
@@ -307,8 +313,8 @@ class PatchTextAggregation(nn.Module):
         self.similarity_threshold = similarity_threshold
         # plain attributes on purpose: the towers must not enter teacher.state_dict()
         object.__setattr__(self, "_clip", clip_model)
-        self.text_tokenizer = CLIPTextTokenizer(clip_model, tokenizer)
-        self.patch_tokenizer = CLIPPatchTokenizer(clip_model)
+        self.text_tokenizer = CLIPTextTokenizer(clip_model, tokenizer, precision=tower_precision)
+        self.patch_tokenizer = CLIPPatchTokenizer(clip_model, precision=tower_precision)
         self.cross_modal_attention = CrossModalAttention(embed_dim, num_heads)
         self.knn_cache = {}
         self.use_knn_projection = False

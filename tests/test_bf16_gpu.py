@@ -62,3 +62,48 @@ def test_frozen_vision_tower_bf16_error(name, mk):
     assert rel < 3e-2 and float(cos) > 0.999
     with pytest.raises(RuntimeError):
         m.get_image_features(pixel_values=pix, precision="bf16")          # grads enabled + trainable params
+
+
+def test_frozen_text_tower_bf16_error():
+    from dclip_amd.clip_model import from_hf_state_dict
+    dev = torch.device("cuda:0")
+    cfg = dcfg.vit_b32()
+    m = from_hf_state_dict(cfg, synth.synth_clip_state_dict(cfg, seed=0, gain=3.0), device=dev)
+    ids = synth.synth_input_ids(6, cfg.text, seed=3, ragged=True).to(dev)
+    with torch.no_grad():
+        f32 = m.get_text_features(input_ids=ids)
+        b16 = m.get_text_features(input_ids=ids, precision="bf16")
+        s32, t32, e32 = m.text_token_level(ids)
+        s16, t16, e16 = m.text_token_level(ids, precision="bf16")
+    assert torch.equal(e32, e16)
+    for nm, a, b in (("sentence", f32, b16), ("sentence(token pass)", s32, s16)):
+        rel = float((a - b).abs().max() / a.abs().max())
+        cos = float(torch.nn.functional.cosine_similarity(a, b, dim=1).min())
+        print(f"text {nm}: bf16 max rel err {rel:.2e}, min cosine {cos:.6f}")
+        assert rel < 3e-2 and cos > 0.999
+    # word tokens that the teacher reads: rows 1..eos-1 of each caption
+    for b in range(ids.shape[0]):
+        n = int(e32[b])
+        cos = torch.nn.functional.cosine_similarity(t32[b, 1:n], t16[b, 1:n], dim=1)
+        assert float(cos.min()) > 0.999
+
+
+def test_meta_teacher_bf16_towers_close_to_fp32():
+    """compute_global_embedding with tower_precision='bf16' vs 'fp32': same cross-attention weights."""
+    from dclip_amd.clip_model import from_hf_state_dict
+    from dclip_amd.patch_text_aggregation import PatchTextAggregation
+    dev = torch.device("cuda:0")
+    cfg = dcfg.vit_b32()
+    clip = from_hf_state_dict(cfg, synth.synth_clip_state_dict(cfg, seed=0, gain=3.0), device=dev)
+    E = cfg.projection_dim
+    outs = {}
+    for prec in ("fp32", "bf16"):
+        t = PatchTextAggregation(embed_dim=E, num_heads=E // 64, clip_model=clip, tower_precision=prec).to(dev)
+        t.cross_modal_attention.load_state_dict(synth.synth_cross_modal_state_dict(E, seed=5))
+        regions = synth.synth_regions(3, 4, cfg.vision, seed=2).to(dev)
+        ids = synth.synth_input_ids(3, cfg.text, seed=3, ragged=True).to(dev)
+        with torch.no_grad():
+            outs[prec] = t.compute_global_embedding_tensors(regions, ids, torch.tensor([4, 2, 0], dtype=torch.int32))
+    cos = torch.nn.functional.cosine_similarity(outs["fp32"], outs["bf16"], dim=1)
+    print("meta-teacher bf16 towers: min cosine", float(cos.min()))
+    assert float(cos.min()) > 0.999
