@@ -54,7 +54,8 @@ class CLIPImageDistillation(LightningLikeModule):
         self.temperature = 0.05
         if teacher is None:
             from .patch_text_aggregation import PatchTextAggregation
-            teacher = PatchTextAggregation(embed_dim=self.student.config.projection_dim, clip_model=self.student)
+            E = self.student.config.projection_dim               # 512 / 8 heads in the reference (:446-452)
+            teacher = PatchTextAggregation(embed_dim=E, num_heads=max(1, E // 64), clip_model=self.student)
         self.teacher = teacher
         if contrastive_teacher_path:
             # weights_only: a checkpoint is data, nothing in it is executed (training/CLIP_image_distillation.py:458-462)
@@ -104,13 +105,24 @@ class CLIPImageDistillation(LightningLikeModule):
         return functional.cosine_distillation_loss(student_embeddings, teacher_embeddings)
 
     def _tokenize(self, captions):
+        if isinstance(captions, torch.Tensor):
+            return captions
         if self.preprocess is None:
             raise RuntimeError("caption strings need clip_preprocess (an HF CLIPProcessor loaded from a local path)")
         return self.preprocess(text=captions, return_tensors="pt", padding=True, truncation=True)["input_ids"]
 
     def _step(self, batch, log_name: str, bs_field: str):
         dev = self.device
-        if isinstance(batch, dict):
+        if isinstance(batch, dict) and "captions" in batch:
+            # data.GpuCollate: decoded images already on the device, student preprocessing done there
+            images = batch["pixel_values"].to(dev)
+            tokens = self._tokenize(batch["captions"]).to(dev)
+            with torch.no_grad():
+                teacher_image = self.teacher.compute_global_embedding_batch(
+                    batch["image_paths"], tokens, batch["weighted_boxes"], batch.get("images_u8"),
+                    batch.get("dims")).to(dev).float()
+            teacher_text = None
+        elif isinstance(batch, dict):
             images = batch["pixel_values"].to(dev)
             tokens = batch["input_ids"].to(dev)
             with torch.no_grad():
@@ -178,6 +190,29 @@ class CLIPImageDistillation(LightningLikeModule):
 
         scheduler = torch.optim.lr_scheduler.LambdaLR(optimizer, lr_lambda)
         return [optimizer], [scheduler]
+
+    # ------------------------------------------------------------------ loaders (:685-693)
+    def _dataset(self, json_file, cache_filename):
+        from .data import MultiModalDataset
+        return MultiModalDataset(json_file, self.preprocess, cache_dir=getattr(self.hparams, "cache_dir", "./cache"),
+                                 cache_filename=cache_filename, detector=getattr(self, "detector", None))
+
+    def train_dataloader(self):
+        """N3: the reference batches the TRAINING set with eval_batch_size (:687); kept."""
+        from torch.utils.data import DataLoader
+        from .data import MultiModalDataset
+        ds = self._dataset(self.hparams.train_file, getattr(self.hparams, "train_cache_filename", "train_precache.pkl"))
+        return DataLoader(ds, batch_size=self.hparams.eval_batch_size, num_workers=0, pin_memory=True, shuffle=True,
+                          collate_fn=MultiModalDataset.custom_collate_fn)
+
+    def val_dataloader(self):
+        from torch.utils.data import DataLoader
+        from .data import MultiModalDataset
+        if not getattr(self.hparams, "val_file", None):
+            return None
+        ds = self._dataset(self.hparams.val_file, getattr(self.hparams, "val_cache_filename", "val_precache.pkl"))
+        return DataLoader(ds, batch_size=self.hparams.eval_batch_size, num_workers=0, pin_memory=False,
+                          collate_fn=MultiModalDataset.custom_collate_fn)
 
     @staticmethod
     def add_model_specific_args(parent_parser: argparse.ArgumentParser) -> argparse.ArgumentParser:

@@ -60,6 +60,8 @@ SIGNATURES = {
     "dclip_rank_count": (I, [P, P, P, P, P, I, I, I, P, Z, P]),
     "dclip_crop_resize_workspace": (Z, [I, I, I, I]),
     "dclip_crop_resize_u8": (I, [P, P, P, P, I, I, I, I, I, I, I, P, Z, P]),
+    "dclip_clip_preprocess_workspace": (Z, [I, I, I, I]),
+    "dclip_clip_preprocess_u8": (I, [P, P, P, I, I, I, I, P, P, P, Z, P]),
     "dclip_gemm_bf16": (I, [P, P, P, P, P, I, I, I, I, I, I, I, I, P]),
     "dclip_cast_f32_bf16": (I, [P, P, I, I, I, I, P]),
     "dclip_layernorm_fwd_bf16": (I, [P, P, P, P, I, I, F, P]),

@@ -601,6 +601,32 @@ def crop_resize(images_u8: torch.Tensor, dims: torch.Tensor, boxes: torch.Tensor
     return out
 
 
+CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)
+CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
+
+
+def clip_preprocess(images_u8: torch.Tensor, dims: torch.Tensor, size: int = 224, mean=CLIP_MEAN, std=CLIP_STD) -> torch.Tensor:
+    """images_u8 [B,Hmax,Wmax,3] uint8 (image b in the top-left dims[b]=(h,w) corner) -> pixel_values [B,3,S,S] fp32:
+    shortest-edge BICUBIC resize, centre crop, 1/255, (x-mean)/std — bit-exact with HF CLIPImageProcessor (PIL)."""
+    import ctypes
+    lib = _lib.load()
+    if not (images_u8.is_cuda and images_u8.dtype == torch.uint8 and images_u8.is_contiguous() and images_u8.dim() == 4
+            and images_u8.shape[3] == 3):
+        raise ValueError("clip_preprocess: images must be a contiguous uint8 CUDA tensor [B,H,W,3]")
+    B, Hmax, Wmax, _ = images_u8.shape
+    if not (dims.is_cuda and dims.dtype == torch.int32 and dims.is_contiguous() and tuple(dims.shape) == (B, 2)):
+        raise ValueError("clip_preprocess: dims must be a contiguous int32 CUDA tensor [B,2]")
+    out = torch.empty((B, 3, size, size), dtype=torch.float32, device=images_u8.device)
+    nbytes = lib.dclip_clip_preprocess_workspace(B, Hmax, Wmax, size)
+    ws = _ws.get(nbytes, images_u8.device)
+    m = (ctypes.c_float * 3)(*[float(v) for v in mean])
+    s = (ctypes.c_float * 3)(*[float(v) for v in std])
+    _lib.check(lib.dclip_clip_preprocess_u8(images_u8.data_ptr(), dims.data_ptr(), out.data_ptr(), B, Hmax, Wmax, size,
+                                            ctypes.cast(m, ctypes.c_void_p), ctypes.cast(s, ctypes.c_void_p), _ptr(ws),
+                                            nbytes, _stream()), "clip_preprocess_u8")
+    return out
+
+
 # ------------------------------------------------------------------------------------------- evaluation
 
 def rowdot_gather(a, b, idx=None):

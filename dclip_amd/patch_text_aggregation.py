@@ -241,18 +241,25 @@ class CLIPPatchTokenizer:
         arr = np.asarray(pil_patch.convert("RGB").resize((s, s), Image.BILINEAR), dtype=np.float32) / 255.0
         return torch.from_numpy(arr).permute(2, 0, 1).contiguous()
 
-    def crop_boxes_gpu(self, images: Sequence, boxes_per_image: Sequence[Sequence]) -> tuple:
+    def crop_boxes_gpu(self, images: Sequence, boxes_per_image: Sequence[Sequence], images_u8: Optional[torch.Tensor] = None,
+                       dims: Optional[torch.Tensor] = None) -> tuple:
         """PIL images (or HWC uint8 arrays) + per-image box lists -> (regions [B,Rmax,3,S,S] in [0,1], counts [B]).
-        The crops are cut, resized and converted on the GPU, bit-exact with `patch_transform` (Pillow)."""
+        The crops are cut, resized and converted on the GPU, bit-exact with `patch_transform` (Pillow).
+        `images_u8` [B,Hmax,Wmax,3] + `dims` [B,2] (already on the device, data.GpuCollate) replace `images`."""
         import numpy as np
         dev = self.device
         s = self.clip_model.config.vision.image_size
-        arrs = [np.asarray(im.convert("RGB") if hasattr(im, "convert") else im, dtype=np.uint8) for im in images]
-        B = len(arrs)
-        hmax, wmax = max(a.shape[0] for a in arrs), max(a.shape[1] for a in arrs)
-        batch = np.zeros((B, hmax, wmax, 3), dtype=np.uint8)
-        for b, a in enumerate(arrs):
-            batch[b, :a.shape[0], :a.shape[1]] = a
+        if images_u8 is None:
+            arrs = [np.asarray(im.convert("RGB") if hasattr(im, "convert") else im, dtype=np.uint8) for im in images]
+            hmax, wmax = max(a.shape[0] for a in arrs), max(a.shape[1] for a in arrs)
+            batch = np.zeros((len(arrs), hmax, wmax, 3), dtype=np.uint8)
+            for b, a in enumerate(arrs):
+                batch[b, :a.shape[0], :a.shape[1]] = a
+            images_u8 = torch.from_numpy(batch).to(dev)
+            dims = torch.tensor([a.shape[:2] for a in arrs], dtype=torch.int32).to(dev)
+        B = images_u8.shape[0]
+        if len(boxes_per_image) != B:
+            raise ValueError("crop_boxes_gpu: one box list per image")
         flat, counts = [], []
         for b, boxes in enumerate(boxes_per_image):
             counts.append(len(boxes))
@@ -264,9 +271,8 @@ class CLIPPatchTokenizer:
         regions = torch.zeros((B, rmax, 3, s, s), dtype=torch.float32, device=dev)
         if flat:
             bx = torch.tensor(flat, dtype=torch.int32)
-            crops = ops.crop_resize(torch.from_numpy(batch).to(dev), torch.tensor([a.shape[:2] for a in arrs], dtype=torch.int32
-                                                                                  ).to(dev), bx.to(dev), s,
-                                    int((bx[:, 4] - bx[:, 2]).max()), int((bx[:, 3] - bx[:, 1]).max()))
+            crops = ops.crop_resize(images_u8, dims, bx.to(dev), s, int((bx[:, 4] - bx[:, 2]).max()),
+                                    int((bx[:, 3] - bx[:, 1]).max()))
             o = 0
             for b, n in enumerate(counts):
                 if n:
@@ -368,19 +374,25 @@ class PatchTextAggregation(nn.Module):
         return GlobalPoolFn.apply(at, ai, 2.0)
 
     # ---- the reference's path-based signature
-    def compute_global_embedding_batch(self, image_paths, texts, weighted_boxes_batch=None):
-        """:268-656 with cached boxes: images are decoded on the host; crops, resize and everything after run batched on the GPU."""
+    def compute_global_embedding_batch(self, image_paths, texts, weighted_boxes_batch=None, images_u8=None, dims=None):
+        """:268-656 with cached boxes: images are decoded on the host; crops, resize and everything after run batched
+        on the GPU.  `images_u8` / `dims` (data.GpuCollate) hand over images that are already decoded and uploaded.
+        `texts`: caption strings (needs a tokenizer) or an [B,T] id tensor."""
         from PIL import Image
         if weighted_boxes_batch is None:
             raise NotImplementedError("no detector here: pass weighted_boxes_batch (the reference's loader does)")
         if isinstance(weighted_boxes_batch, list):
-            weighted_boxes_batch = dict(zip(image_paths, weighted_boxes_batch))
-        images = []
-        for path in image_paths:
-            try:
-                images.append(Image.open(path).convert("RGB"))
-            except Exception:
-                images.append(Image.new("RGB", (224, 224)))            # the reference's fallback (:302)
-        regions, counts = self.patch_tokenizer.crop_boxes_gpu(images, [weighted_boxes_batch.get(p, []) for p in image_paths])
-        ids = self.text_tokenizer._ids(list(texts))
+            boxes = weighted_boxes_batch
+        else:
+            boxes = [weighted_boxes_batch.get(p, []) for p in image_paths]
+        images = None
+        if images_u8 is None:
+            images = []
+            for path in image_paths:
+                try:
+                    images.append(Image.open(path).convert("RGB"))
+                except Exception:
+                    images.append(Image.new("RGB", (224, 224)))        # the reference's fallback (:302)
+        regions, counts = self.patch_tokenizer.crop_boxes_gpu(images, boxes, images_u8, dims)
+        ids = self.text_tokenizer._ids(texts if isinstance(texts, torch.Tensor) else list(texts))
         return self.compute_global_embedding_tensors(regions, ids, counts)

@@ -122,3 +122,21 @@ def synth_input_ids(batch: int, cfg: TextConfig, seed: int = 3, ragged: bool = F
 def synth_embeddings(batch: int, dim: int, seed: int = 1) -> torch.Tensor:
     gen = torch.Generator().manual_seed(seed)
     return torch.randn((batch, dim), generator=gen)
+
+
+def synth_photo(height: int, width: int, seed: int = 0):
+    """HWC uint8 RGB test image: smooth colour gradients + a few hard edges + noise, so that resampling filters
+    (antialiasing, negative bicubic lobes, clipping at 0 / 255) all matter.  numpy RandomState: stable across hosts."""
+    import numpy as np
+    rs = np.random.RandomState(seed)
+    yy, xx = np.mgrid[0:height, 0:width].astype(np.float64)
+    img = np.zeros((height, width, 3), dtype=np.float64)
+    for c in range(3):
+        fx, fy, ph = rs.uniform(0.5, 6.0), rs.uniform(0.5, 6.0), rs.uniform(0, 6.28)
+        img[..., c] = 127.5 + 110.0 * np.sin(fx * xx / width * 6.28 + fy * yy / height * 6.28 + ph)
+    for _ in range(6):                                   # saturated rectangles: hard edges at 0 and 255
+        y0, x0 = rs.randint(0, height), rs.randint(0, width)
+        y1, x1 = min(height, y0 + rs.randint(1, max(2, height // 3))), min(width, x0 + rs.randint(1, max(2, width // 3)))
+        img[y0:y1, x0:x1] = rs.choice([0.0, 255.0], size=3)
+    img += rs.normal(0.0, 12.0, size=img.shape)
+    return np.clip(np.rint(img), 0, 255).astype(np.uint8)

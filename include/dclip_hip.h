@@ -245,6 +245,17 @@ int dclip_crop_resize_u8(const uint8_t* images, const int32_t* dims, const int32
                          int Hmax, int Wmax, int NR, int S, int max_crop_h, int max_crop_w, void* workspace,
                          size_t workspace_bytes, void* stream);
 
+/* Student-side image preprocessing (the `clip_preprocess(images=...)` call of MultiModalDataset.__getitem__,
+ * training/CLIP_image_distillation.py:349-350; arithmetic = HF CLIPImageProcessor, PIL backend): decoded RGB uint8
+ * images -> shortest edge resized to S with Pillow's BICUBIC two-pass 8-bit resample (long edge = int(S*long/short)),
+ * centred S x S window, float32(float64(v) * (1/255)), then (x - mean) / std in fp32, CHW.  Bit-exact with the host
+ * library.  images [B,Hmax,Wmax,3] (each image in the top-left dims[b] = (h,w) corner); mean/stdv are HOST float[3].
+ */
+size_t dclip_clip_preprocess_workspace(int B, int Hmax, int Wmax, int S);
+int dclip_clip_preprocess_u8(const uint8_t* images, const int32_t* dims, float* out, int B, int Hmax, int Wmax, int S,
+                             const float* mean, const float* stdv, void* workspace, size_t workspace_bytes,
+                             void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * bf16 forward path for FROZEN towers (BASELINE configs c3 / c5, "bf16 MFMA"): the teacher's region encoder
  * (training/image_tokenizer.py:119-120) and the frozen text tower never need gradients, so their GEMMs may run on

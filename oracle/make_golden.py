@@ -431,6 +431,86 @@ def gen_eval():
     save("eval_retrieval.npz", **arrs)
 
 
+# ----------------------------------------------------------------------------- input side
+
+PHOTO_SIZES = [(300, 400), (400, 300), (224, 224), (97, 130), (513, 224), (640, 481), (224, 1000), (60, 60)]
+
+
+def gen_data():
+    """(1) HF CLIPImageProcessor (PIL backend: what the reference's `clip_preprocess(images=...)` computes) on seeded
+    images -> sha256 of the float32 bytes + a few probes.  (2) The reference's `MultiModalDataset` and
+    `load_or_compute_yolo`, lifted by `ast` from training/CLIP_image_distillation.py (the module itself is not
+    importable: it fetches models at import), run over a generated JSON + box cache."""
+    import hashlib
+    import json
+    import pickle
+    import random
+    from PIL import Image
+    from torch.utils.data import Dataset
+    from transformers import CLIPImageProcessor
+    from dclip_amd import synth
+
+    proc = CLIPImageProcessor()
+    arrs = {"sizes": np.array(PHOTO_SIZES), "processor": np.array(type(proc).__name__)}
+    for i, (h, w) in enumerate(PHOTO_SIZES):
+        img = synth.synth_photo(h, w, seed=100 + i)
+        pv = proc(images=Image.fromarray(img), return_tensors="pt")["pixel_values"][0].numpy()
+        assert pv.dtype == np.float32 and pv.shape == (3, 224, 224)
+        arrs[f"sha_{i}"] = np.array(hashlib.sha256(np.ascontiguousarray(pv).tobytes()).hexdigest())
+        arrs[f"probe_{i}"] = np.array([pv.astype(np.float64).sum(), pv[0, 0, 0], pv[1, 111, 57], pv[2, 223, 223]])
+
+    src = open(os.path.join(REF, "training", "CLIP_image_distillation.py")).read()
+    want = {"load_or_compute_yolo", "MultiModalDataset"}
+    nodes = [n for n in ast.parse(src).body if isinstance(n, (ast.FunctionDef, ast.ClassDef)) and n.name in want]
+    ns = {"os": os, "pickle": pickle, "json": json, "torch": torch, "Image": Image, "random": random, "Dataset": Dataset,
+          "print": lambda *a, **k: None}
+    exec(compile(ast.Module(body=nodes, type_ignores=[]), "<lifted>", "exec"), ns)
+
+    def shim(images=None, text=None, return_tensors="pt"):
+        return proc(images=images, return_tensors=return_tensors)
+
+    with tempfile.TemporaryDirectory() as td:
+        recs, cache = [], {}
+        rs = np.random.RandomState(5)
+        for i, (h, w) in enumerate(PHOTO_SIZES[:6]):
+            path = os.path.join(td, f"img_{i}.png")
+            Image.fromarray(synth.synth_photo(h, w, seed=100 + i)).save(path)
+            rec = {"image_path": path}
+            if i % 2 == 0:
+                rec["captions"] = [f"caption {i}-{j}" for j in range(3)]
+            else:
+                rec["caption"] = f"single caption {i}"
+            recs.append(rec)
+            nb = int(rs.randint(0, 4))
+            boxes = []
+            for _ in range(nb):
+                x1, y1 = int(rs.randint(0, w - 8)), int(rs.randint(0, h - 8))
+                boxes.append(((x1, y1, int(rs.randint(x1 + 4, w + 1)), int(rs.randint(y1 + 4, h + 1))), float(rs.rand())))
+            cache[path] = boxes
+        recs.append({"image_path": os.path.join(td, "missing.png"), "caption": "broken"})     # retry path (:387-398)
+        cache[recs[-1]["image_path"]] = []
+        jf = os.path.join(td, "train.json")
+        json.dump(recs, open(jf, "w"))
+        cdir = os.path.join(td, "cache")
+        os.makedirs(cdir)
+        pickle.dump(cache, open(os.path.join(cdir, "train_precache.pkl"), "wb"), protocol=4)
+        ds = ns["MultiModalDataset"](jf, shim, cache_dir=cdir, use_batch_cache=True, cache_filename="train_precache.pkl")
+        random.seed(1234)
+        items = [ds[i] for i in range(len(ds))]
+        arrs["n_items"] = np.array(len(items))
+        arrs["records_json"] = np.array(json.dumps([{k: (os.path.basename(v) if k == "image_path" else v)
+                                                     for k, v in r.items()} for r in recs]))
+        arrs["cache_json"] = np.array(json.dumps({os.path.basename(k): v for k, v in cache.items()}))
+        for i, (pv, cap, path, boxes) in enumerate(items):
+            arrs[f"item_sha_{i}"] = np.array(hashlib.sha256(np.ascontiguousarray(pv.numpy()).tobytes()).hexdigest())
+            arrs[f"item_caption_{i}"] = np.array(cap)
+            arrs[f"item_path_{i}"] = np.array(os.path.basename(path))
+            arrs[f"item_boxes_{i}"] = np.array(json.dumps(boxes))
+        pvs, caps, paths, boxes = ns["MultiModalDataset"].custom_collate_fn(items[:3])
+        arrs["collate_shape"] = np.array(pvs.shape)
+    save("data_front.npz", **arrs)
+
+
 def main():
     which = set(sys.argv[1:])
     pta, tt, it = import_reference_teacher()
@@ -449,6 +529,8 @@ def main():
         gen_step_c1(ref_con, ref_cos)
     if not which or "eval" in which:
         gen_eval()
+    if not which or "data" in which:
+        gen_data()
 
 
 if __name__ == "__main__":
