@@ -76,10 +76,18 @@ class GemmTimer:
             e0.record()
             out = inner(a, b, layout, **kw)
             e1.record()
-            timer.records.append((2.0 * M * N * K, e0, e1))
+            timer.records.append((2.0 * M * N * K, e0, e1, (M, N, K, layout)))
             return out
 
         ops.gemm = timed_gemm
+
+    def by_shape(self):
+        """{(M,N,K,layout): (launches, total ms, TFLOP/s)} — tuning aid (DCLIP_BENCH_SHAPES=1 prints it to stderr)."""
+        agg = {}
+        for fl, e0, e1, key in self.records:
+            n, ms, f = agg.get(key, (0, 0.0, 0.0))
+            agg[key] = (n + 1, ms + e0.elapsed_time(e1), f + fl)
+        return {k: (n, ms, f / (ms * 1e-3) / 1e12) for k, (n, ms, f) in agg.items()}
 
     def summary(self):
         flops = sum(r[0] for r in self.records)
@@ -130,6 +138,13 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-optimizer", action="store_true", help="time forward+backward only")
     ap.add_argument("--no-gemm-events", action="store_true", help="do not bracket GEMM launches with HIP events")
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3"],
+                    help="c2 (default, the benched config): teacher image embedding given.  c3: the meta-teacher runs "
+                         "inside the step on --regions crops per image (separate frozen teacher CLIP of --teacher-model)")
+    ap.add_argument("--regions", type=int, default=8)
+    ap.add_argument("--teacher-model", default=None, choices=list(dcfg.NAMED))
+    ap.add_argument("--tower-precision", default="fp32", choices=["fp32", "bf16"],
+                    help="c3 only: GEMM input precision of the FROZEN teacher towers (student is always fp32)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -156,8 +171,19 @@ def main():
 
     cfg = dcfg.NAMED[args.model]()
     student = from_hf_state_dict(cfg, synth.synth_clip_state_dict(cfg, seed=0), device=dev)   # same init on all ranks
-    teacher = PatchTextAggregation(embed_dim=cfg.projection_dim, num_heads=cfg.projection_dim // 64,
-                                   clip_model=student).to(dev)
+    tcfg = None
+    if args.workload == "c3":
+        tcfg = dcfg.NAMED[args.teacher_model or args.model]()
+        if tcfg.projection_dim != cfg.projection_dim:
+            raise SystemExit("teacher and student must share the embedding width")
+        teacher_clip = from_hf_state_dict(tcfg, synth.synth_clip_state_dict(tcfg, seed=7), device=dev)
+        for p_ in teacher_clip.parameters():
+            p_.requires_grad = False
+        teacher = PatchTextAggregation(embed_dim=cfg.projection_dim, num_heads=cfg.projection_dim // 64,
+                                       clip_model=teacher_clip, tower_precision=args.tower_precision).to(dev)
+    else:
+        teacher = PatchTextAggregation(embed_dim=cfg.projection_dim, num_heads=cfg.projection_dim // 64,
+                                       clip_model=student).to(dev)
     hp = argparse.Namespace(learning_rate=1e-6, warmup_steps=0, total_steps=10 ** 6, train_batch_size=args.batch,
                             eval_batch_size=args.batch)
     module = CLIPImageDistillation(hp, student, None, teacher=teacher, freeze_mode="north_star",
@@ -173,8 +199,11 @@ def main():
     batch = {                                                     # resident in HBM before the timed region
         "pixel_values": synth.synth_pixel_values(B, cfg.vision, seed=rank).to(dev),
         "input_ids": synth.synth_input_ids(B, cfg.text, seed=100 + rank).to(dev),
-        "teacher_image_emb": synth.synth_embeddings(B, cfg.projection_dim, seed=1000 + rank).to(dev),
     }
+    if args.workload == "c3":
+        batch["regions"] = synth.synth_regions(B, args.regions, tcfg.vision, seed=2000 + rank).to(dev)
+    else:
+        batch["teacher_image_emb"] = synth.synth_embeddings(B, cfg.projection_dim, seed=1000 + rank).to(dev)
 
     timer = GemmTimer()
     if not args.no_gemm_events:
@@ -218,8 +247,18 @@ def main():
         ms_per_step = elapsed * 1e3 / args.steps
         value = world * B * args.steps / elapsed
         step_flops = step_flops_per_image(cfg, T) * B
+        teacher_flops = 0.0
+        if args.workload == "c3":      # + R frozen region forwards + the teacher's own text forward + cross-attention
+            E, R = cfg.projection_dim, args.regions
+            teacher_flops = B * (R * (vision_fwd_flops(tcfg.vision) + 2.0 * tcfg.vision.hidden_size * E)
+                                 + text_fwd_flops(tcfg.text, T) + 2.0 * T * tcfg.text.hidden_size * E
+                                 + 8.0 * E * E * (T + R) + 8.0 * T * R * E)
         gflops, gms, glaunches = timer.summary() if not args.no_gemm_events else (0.0, 0.0, 0)
         achieved = gflops / (gms * 1e-3) / 1e12 if gms > 0 else None
+        if os.environ.get("DCLIP_BENCH_SHAPES") and not args.no_gemm_events:
+            for (M_, N_, K_, lay), (n, ms, tf) in sorted(timer.by_shape().items(), key=lambda kv: -kv[1][1]):
+                print(f"gemm M={M_:6d} N={N_:5d} K={K_:6d} layout={lay} launches/step={n / args.steps:5.1f} "
+                      f"ms/step={ms / args.steps:7.3f} {tf:6.1f} TF/s", file=sys.stderr)
         traffic = None
         pmc = os.path.join(REPO, "profiles", "gemm_traffic.json")
         if os.path.exists(pmc):
@@ -237,9 +276,14 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"BASELINE config c2: {cfg.name} distill step, bs={B}/GPU, 224x224 + {T}-token "
-                                   f"synthetic pairs, contrastive+cosine loss, fp32, vision trainable / text frozen "
-                                   f"(north_star regime), " + ("fwd+bwd only" if opt is None else "fwd+bwd + clip-norm 0.5 + AdamW"),
+            "config": {"workload": (f"BASELINE config c2: {cfg.name} distill step, bs={B}/GPU, 224x224 + {T}-token "
+                                    f"synthetic pairs, contrastive+cosine loss, fp32, vision trainable / text frozen "
+                                    f"(north_star regime), " if args.workload == "c2" else
+                                    f"BASELINE config c3 (extra, not the benched config): {cfg.name} student fp32 + "
+                                    f"meta-teacher in the step ({args.regions} region crops/img through a frozen "
+                                    f"{tcfg.name} tower with {args.tower_precision} GEMM inputs, token-level text, "
+                                    f"cross-modal attention + aggregation), bs={B}/GPU, ")
+                                   + ("fwd+bwd only" if opt is None else "fwd+bwd + clip-norm 0.5 + AdamW"),
                        "global_batch": world * B, "parallelism": f"dp{world}",
                        "loss": float(last.detach())},
             "roofline": {"bound": "mfma", "kernel": "gemm_f32_kernel (v_mfma_f32_32x32x2_f32)",
@@ -260,6 +304,15 @@ def main():
                                   gflops / max(1, args.steps) / (ms_per_step * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
                               "flops_per_image": step_flops_per_image(cfg, T)},
         }
+        if args.workload == "c3":
+            # mixed-precision floor: student flops at the fp32 matrix peak + frozen-teacher flops at the peak of the
+            # precision they were multiplied in (bf16 dense 2500 TF/s, MI355X_MICROARCH.md)
+            tpeak = 2500.0 if args.tower_precision == "bf16" else PEAK_F32_MFMA_TFLOPS
+            t_min_ms = (step_flops / PEAK_F32_MFMA_TFLOPS + teacher_flops / tpeak) / 1e9
+            line["roofline_step"] = {"bound": "mfma", "unit": "ms", "floor_ms": round(t_min_ms, 3),
+                                     "frac": round(t_min_ms / ms_per_step, 4),
+                                     "student_flops_per_image": step_flops / B, "teacher_flops_per_image": teacher_flops / B,
+                                     "teacher_peak_tflops": tpeak}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)

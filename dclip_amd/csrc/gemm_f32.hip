@@ -36,6 +36,7 @@ struct GemmParams {
   int tiles_m, tiles_n;
   int k_per_split;  // multiple of BK
   float* slab;      // split-K partials [split][M][N] or nullptr
+  float* rs_slab;   // A_ROWSUM under split-K: partials [split][M]
   // contrastive-loss modes (mode 0 = plain GEMM)
   int mode;              // 1: row-LSE partials over this tile's columns, 2: dZ tile, 3: per-row count of z > lse_row[row]
   const float* lse_row;  // mode 2
@@ -110,6 +111,13 @@ __global__ void __launch_bounds__(256, 2) gemm_f32_kernel(GemmParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  // DCLIP_EPI_A_ROWSUM: sum_k A[m][k] is accumulated from the staged chunks of a [K][M]-major A while they sit in
+  // registers (every chunk of a thread covers the same 4 columns m: 256 % (BM/4) == 0); the workgroups of tile
+  // column 0 reduce across threads through LDS after the K loop and store.
+  static_assert(256 % (BM / 4) == 0, "a thread's A chunks must share their m columns");
+  const bool do_rs = !A_KMAJOR && (p.epilogue & DCLIP_EPI_A_ROWSUM) && tile_n == 0;   // workgroup-uniform
+  f32x4 rs4 = {0.f, 0.f, 0.f, 0.f};
+
   f32x4 ra[A_CHUNKS], rb[B_CHUNKS];
 
   // ---- staging through buffer loads -------------------------------------------------------------------------
@@ -173,6 +181,7 @@ __global__ void __launch_bounds__(256, 2) gemm_f32_kernel(GemmParams p) {
         *reinterpret_cast<f32x4*>(a + row * BK + ((slot ^ ((row >> 1) & 7)) << 2)) = v;
       } else {
         *reinterpret_cast<f32x4*>(a + id * 4) = v;  // [kk][BM] is exactly chunk order
+        rs4 += v;
       }
     }
 #pragma unroll
@@ -286,6 +295,14 @@ __global__ void __launch_bounds__(256, 2) gemm_f32_kernel(GemmParams p) {
           store_chunk(buf ^ 1, step - FIRST);
           __builtin_amdgcn_sched_barrier(0);  // one LDS write per MFMA step, in this order
         }
+        if (!A_KMAJOR && step == FIRST + NCH) {
+          // every staged chunk has landed and is in LDS: fold the A chunks into the row sums BEHIND this step's
+          // MFMAs (placed ahead of an MFMA, even four independent adds delay its issue and cost ~6 % of the tile)
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int c = 0; c < A_CHUNKS; ++c) rs4 += ra[c];
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
     }
   };
@@ -308,6 +325,20 @@ __global__ void __launch_bounds__(256, 2) gemm_f32_kernel(GemmParams p) {
     if (kt + 1 < nk) {
       if (k_ragged && kt + 2 == nk) store_tile(buf ^ 1, kt + 1, true);
       else store_tile(buf ^ 1, kt + 1, false);
+    }
+    __syncthreads();
+  }
+
+  if (do_rs) {   // all LDS reads of the K loop are behind the last barrier: reuse the tile space
+    *reinterpret_cast<f32x4*>(lds + tid * 4) = rs4;
+    __syncthreads();
+    if (tid < BM && m0 + tid < p.M) {
+      constexpr int MC = BM / 4;  // m-chunks per K row; thread t holds chunk t % MC
+      float t = 0.f;
+#pragma unroll
+      for (int kr = 0; kr < 256 / MC; ++kr) t += lds[(kr * MC + tid / 4) * 4 + (tid & 3)];
+      if (p.slab) p.rs_slab[(size_t)blockIdx.y * p.M + m0 + tid] = t;
+      else p.aux[m0 + tid] = t;
     }
     __syncthreads();
   }
@@ -511,6 +542,13 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(GemmParams p, int sp
 #pragma unroll
     for (int e = 0; e < 4; ++e) apply_epilogue_store(p, row, col + e, s[e]);
   }
+  if (p.epilogue & DCLIP_EPI_A_ROWSUM) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < p.M; i += gridDim.x * blockDim.x) {
+      float t = p.rs_slab[i];
+      for (int z = 1; z < splits; ++z) t += p.rs_slab[(size_t)z * p.M + i];
+      p.aux[i] = t;
+    }
+  }
 }
 
 template <int BM, int BN, int WM, int WN>
@@ -580,7 +618,7 @@ Plan make_plan(int M, int N, int K, int layout, int split_k) {
 
 DCLIP_API size_t dclip_gemm_f32_workspace(int M, int N, int K, int layout, int split_k) {
   Plan pl = make_plan(M, N, K, layout, split_k);
-  return pl.splits > 1 ? (size_t)pl.splits * M * N * sizeof(float) : 0;
+  return pl.splits > 1 ? (size_t)pl.splits * ((size_t)M * N + M) * sizeof(float) : 0;   // C slabs + A_ROWSUM slabs
 }
 
 DCLIP_API int dclip_gemm_f32(const float* A, const float* B, float* C, const float* bias,
@@ -599,6 +637,8 @@ DCLIP_API int dclip_gemm_f32(const float* A, const float* B, float* C, const flo
   DCLIP_REQUIRE(!(epilogue & DCLIP_EPI_BIAS) || bias, "gemm_f32: BIAS without bias");
   DCLIP_REQUIRE(!(epilogue & DCLIP_EPI_RESIDUAL) || residual, "gemm_f32: RESIDUAL without residual");
   DCLIP_REQUIRE(!(epilogue & DCLIP_EPI_DGELU) || aux, "gemm_f32: DGELU without aux");
+  DCLIP_REQUIRE(!(epilogue & DCLIP_EPI_A_ROWSUM) || (aux && !ak && !(epilogue & (DCLIP_EPI_GELU | DCLIP_EPI_DGELU))),
+                "gemm_f32: A_ROWSUM needs aux[M], a [K][M]-major A and no GELU/DGELU (they use aux too)");
 
   Plan pl = make_plan(M, N, K, layout, split_k);
   // buffer descriptors address 2^31-1 bytes from a work item's origin: a [K][M]-major operand spans k_per_split rows
@@ -609,15 +649,16 @@ DCLIP_API int dclip_gemm_f32(const float* A, const float* B, float* C, const flo
   DCLIP_REQUIRE((double)128 * (ak ? lda : 1) * 4.0 < 2147483647.0 && (double)128 * (bk ? ldb : 1) * 4.0 < 2147483647.0,
                 "gemm_f32: leading dimension too large");
   GemmParams p{A, B, C, bias, residual, aux, M, N, K, lda, ldb, ldc, epilogue, alpha,
-               cdiv(M, pl.bm), cdiv(N, pl.bn), pl.k_per_split, nullptr,
+               cdiv(M, pl.bm), cdiv(N, pl.bn), pl.k_per_split, nullptr, nullptr,
                MODE_GEMM, nullptr, nullptr, nullptr, nullptr, 0, nullptr};
   if (pl.splits > 1) {
-    const size_t need = (size_t)pl.splits * M * N * sizeof(float);
+    const size_t need = (size_t)pl.splits * ((size_t)M * N + M) * sizeof(float);
     if (!workspace || workspace_bytes < need) {
       dclip_set_error("gemm_f32: split-K needs %zu workspace bytes, got %zu", need, workspace_bytes);
       return DCLIP_EWORKSPACE;
     }
     p.slab = (float*)workspace;
+    p.rs_slab = p.slab + (size_t)pl.splits * M * N;
   }
   hipStream_t st = (hipStream_t)stream;
   if (pl.bm == 128 && pl.bn == 128) launch_cfg<128, 128, 2, 2>(p, layout, pl.splits, st);
@@ -692,7 +733,7 @@ DCLIP_API int dclip_contrastive_lse(const float* a_local, const float* b_global,
   float* pm = (float*)workspace;
   float* ps = pm + slots * Bl;
   GemmParams p{a_local, b_global, nullptr, nullptr, nullptr, nullptr, Bl, Bg, P, P, P, 0, 0, inv_temp,
-               cdiv(Bl, LOSS_BM), cdiv(Bg, LOSS_BN), cdiv(P, BK) * BK, nullptr,
+               cdiv(Bl, LOSS_BM), cdiv(Bg, LOSS_BN), cdiv(P, BK) * BK, nullptr, nullptr,
                MODE_LSE, nullptr, nullptr, pm, ps, offset, nullptr};
   hipStream_t st = (hipStream_t)stream;
   launch_cfg<LOSS_BM, LOSS_BN, 2, LOSS_WN>(p, DCLIP_A_KMAJOR | DCLIP_B_KMAJOR, 1, st);
@@ -717,7 +758,7 @@ DCLIP_API int dclip_contrastive_grad(const float* a_local, const float* b_global
   hipStream_t st = (hipStream_t)stream;
   // W[i,j] = exp(z_ij - lse_row[i]) + exp(z_ij - lse_col[j]) - 2[j == i+offset]
   GemmParams p{a_local, b_global, W, nullptr, nullptr, nullptr, Bl, Bg, P, P, P, ldw, 0, inv_temp,
-               cdiv(Bl, LOSS_BM), cdiv(Bg, LOSS_BN), cdiv(P, BK) * BK, nullptr,
+               cdiv(Bl, LOSS_BM), cdiv(Bg, LOSS_BN), cdiv(P, BK) * BK, nullptr, nullptr,
                MODE_DZ, lse_row, lse_col, nullptr, nullptr, offset, nullptr};
   launch_cfg<LOSS_BM, LOSS_BN, 2, LOSS_WN>(p, DCLIP_A_KMAJOR | DCLIP_B_KMAJOR, 1, st);
   DCLIP_CHECK_LAUNCH("contrastive_grad.dz");
@@ -780,7 +821,7 @@ DCLIP_API int dclip_rank_count(const float* queries, const float* candidates, co
   }
   float* part = (float*)workspace;
   GemmParams p{queries, candidates, nullptr, nullptr, nullptr, nullptr, Bq, Bk, P, P, P, 0, 0, 1.0f,
-               cdiv(Bq, LOSS_BM), cdiv(Bk, LOSS_BN), cdiv(P, BK) * BK, nullptr,
+               cdiv(Bq, LOSS_BM), cdiv(Bk, LOSS_BN), cdiv(P, BK) * BK, nullptr, nullptr,
                MODE_RANK, thresh, nullptr, nullptr, part, 0, gt};
   hipStream_t st = (hipStream_t)stream;
   launch_cfg<LOSS_BM, LOSS_BN, 2, LOSS_WN>(p, DCLIP_A_KMAJOR | DCLIP_B_KMAJOR, 1, st);

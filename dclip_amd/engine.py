@@ -54,35 +54,35 @@ def layer_fwd(x, p: LayerParams, B: int, S: int, H: int, causal: bool, eps: floa
     return x2, saved
 
 
+def linear_param_grads(dy, x, need_w: bool, need_b: bool, gr: Dict[str, torch.Tensor], wkey: str, bkey: str):
+    """dW = dy^T x and db = colsum(dy) of one nn.Linear.  When both are wanted the bias gradient comes out of the
+    weight-gradient GEMM (DCLIP_EPI_A_ROWSUM): dy is streamed once, no separate column-sum launch."""
+    if need_w and need_b:
+        gr[bkey] = torch.empty((dy.shape[1],), dtype=torch.float32, device=dy.device)
+        gr[wkey] = ops.gemm(dy, x, ops.LAYOUT_TN, a_rowsum=gr[bkey])
+    elif need_w:
+        gr[wkey] = ops.gemm(dy, x, ops.LAYOUT_TN)
+    elif need_b:
+        gr[bkey] = ops.colsum(dy)
+
+
 def layer_bwd(dx2, p: LayerParams, saved, B: int, S: int, H: int, causal: bool, need: Dict[str, bool]):
     """Returns (dx, grads) with grads keyed like LayerParams.FIELDS (missing = not needed)."""
     x, m1, r1, ln1, qkv, attn, lse, x1, m2, r2, ln2, h, g = saved
     gr: Dict[str, torch.Tensor] = {}
-    if need.get("fc2_w"):
-        gr["fc2_w"] = ops.gemm(dx2, g, ops.LAYOUT_TN)
-    if need.get("fc2_b"):
-        gr["fc2_b"] = ops.colsum(dx2)
+    linear_param_grads(dx2, g, bool(need.get("fc2_w")), bool(need.get("fc2_b")), gr, "fc2_w", "fc2_b")
     dh = ops.gemm(dx2, p.fc2_w, ops.LAYOUT_NN, aux=h, epilogue=ops.EPI_DGELU)
-    if need.get("fc1_w"):
-        gr["fc1_w"] = ops.gemm(dh, ln2, ops.LAYOUT_TN)
-    if need.get("fc1_b"):
-        gr["fc1_b"] = ops.colsum(dh)
+    linear_param_grads(dh, ln2, bool(need.get("fc1_w")), bool(need.get("fc1_b")), gr, "fc1_w", "fc1_b")
     dln2 = ops.gemm(dh, p.fc1_w, ops.LAYOUT_NN)
     del dh
     want_ln2 = bool(need.get("ln2_w") or need.get("ln2_b"))
     dx1, dg, db = ops.layernorm_bwd(dln2, x1, p.ln2_w, m2, r2, dresidual=dx2, need_param_grads=want_ln2)
     if want_ln2:
         gr["ln2_w"], gr["ln2_b"] = dg, db
-    if need.get("out_w"):
-        gr["out_w"] = ops.gemm(dx1, attn, ops.LAYOUT_TN)
-    if need.get("out_b"):
-        gr["out_b"] = ops.colsum(dx1)
+    linear_param_grads(dx1, attn, bool(need.get("out_w")), bool(need.get("out_b")), gr, "out_w", "out_b")
     dattn = ops.gemm(dx1, p.out_w, ops.LAYOUT_NN)
     dqkv = ops.attention_bwd(qkv, attn, dattn, lse, B, S, H, causal)
-    if need.get("qkv_w"):
-        gr["qkv_w"] = ops.gemm(dqkv, ln1, ops.LAYOUT_TN)
-    if need.get("qkv_b"):
-        gr["qkv_b"] = ops.colsum(dqkv)
+    linear_param_grads(dqkv, ln1, bool(need.get("qkv_w")), bool(need.get("qkv_b")), gr, "qkv_w", "qkv_b")
     dln1 = ops.gemm(dqkv, p.qkv_w, ops.LAYOUT_NN)
     del dqkv
     want_ln1 = bool(need.get("ln1_w") or need.get("ln1_b"))
@@ -121,30 +121,18 @@ def last_layer_bwd_cls(dx2, p: LayerParams, saved, B: int, S: int, H: int, need:
     x, m1, r1, ln1, qkv, attn, lse, x1, m2, r2, ln2, h, g = saved
     D = x.shape[1]
     gr: Dict[str, torch.Tensor] = {}
-    if need.get("fc2_w"):
-        gr["fc2_w"] = ops.gemm(dx2, g, ops.LAYOUT_TN)
-    if need.get("fc2_b"):
-        gr["fc2_b"] = ops.colsum(dx2)
+    linear_param_grads(dx2, g, bool(need.get("fc2_w")), bool(need.get("fc2_b")), gr, "fc2_w", "fc2_b")
     dh = ops.gemm(dx2, p.fc2_w, ops.LAYOUT_NN, aux=h, epilogue=ops.EPI_DGELU)
-    if need.get("fc1_w"):
-        gr["fc1_w"] = ops.gemm(dh, ln2, ops.LAYOUT_TN)
-    if need.get("fc1_b"):
-        gr["fc1_b"] = ops.colsum(dh)
+    linear_param_grads(dh, ln2, bool(need.get("fc1_w")), bool(need.get("fc1_b")), gr, "fc1_w", "fc1_b")
     dln2 = ops.gemm(dh, p.fc1_w, ops.LAYOUT_NN)
     want_ln2 = bool(need.get("ln2_w") or need.get("ln2_b"))
     dx1, dg, db = ops.layernorm_bwd(dln2, x1, p.ln2_w, m2, r2, dresidual=dx2, need_param_grads=want_ln2)
     if want_ln2:
         gr["ln2_w"], gr["ln2_b"] = dg, db
-    if need.get("out_w"):
-        gr["out_w"] = ops.gemm(dx1, attn, ops.LAYOUT_TN)
-    if need.get("out_b"):
-        gr["out_b"] = ops.colsum(dx1)
+    linear_param_grads(dx1, attn, bool(need.get("out_w")), bool(need.get("out_b")), gr, "out_w", "out_b")
     dattn = ops.gemm(dx1, p.out_w, ops.LAYOUT_NN)
     dqkv = ops.attention_cls_bwd(qkv, attn, dattn, lse, B, S, H)          # [B*S, 3D]; d q only on the CLS rows
-    if need.get("qkv_w"):
-        gr["qkv_w"] = ops.gemm(dqkv, ln1, ops.LAYOUT_TN)
-    if need.get("qkv_b"):
-        gr["qkv_b"] = ops.colsum(dqkv)
+    linear_param_grads(dqkv, ln1, bool(need.get("qkv_w")), bool(need.get("qkv_b")), gr, "qkv_w", "qkv_b")
     dln1 = ops.gemm(dqkv, p.qkv_w, ops.LAYOUT_NN)
     del dqkv
     want_ln1 = bool(need.get("ln1_w") or need.get("ln1_b"))

@@ -13,7 +13,7 @@ import torch
 from . import _lib
 
 A_KMAJOR, B_KMAJOR = 1, 2
-EPI_BIAS, EPI_GELU, EPI_DGELU, EPI_RESIDUAL, EPI_ACCUM = 1, 2, 4, 8, 16
+EPI_BIAS, EPI_GELU, EPI_DGELU, EPI_RESIDUAL, EPI_ACCUM, EPI_A_ROWSUM = 1, 2, 4, 8, 16, 32
 LAYOUT_NT = A_KMAJOR | B_KMAJOR     # y = x W^T
 LAYOUT_NN = A_KMAJOR                # dx = dy W
 LAYOUT_TN = 0                       # dW = dy^T x
@@ -58,9 +58,10 @@ _ws = _Workspace()
 
 def gemm(a: torch.Tensor, b: torch.Tensor, layout: int, *, out: Optional[torch.Tensor] = None,
          bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
-         aux: Optional[torch.Tensor] = None, epilogue: int = 0, alpha: float = 1.0, split_k: int = 0
-         ) -> torch.Tensor:
-    """C = epilogue(alpha * op(a) @ op(b)); see include/dclip_hip.h for layout / epilogue bits."""
+         aux: Optional[torch.Tensor] = None, epilogue: int = 0, alpha: float = 1.0, split_k: int = 0,
+         a_rowsum: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """C = epilogue(alpha * op(a) @ op(b)); see include/dclip_hip.h for layout / epilogue bits.
+    `a_rowsum` (float[M], [K][M]-major A only) additionally receives sum_k A[m,k]: the bias gradient of a wgrad."""
     lib = _lib.load()
     _f32(a, "a"), _f32(b, "b")
     if a.dim() != 2 or b.dim() != 2:
@@ -90,6 +91,11 @@ def gemm(a: torch.Tensor, b: torch.Tensor, layout: int, *, out: Optional[torch.T
             raise ValueError("gemm: residual shape")
     if aux is not None and tuple(_f32(aux, "aux").shape) != (M, N):
         raise ValueError("gemm: aux shape")
+    if a_rowsum is not None:
+        if aux is not None or (layout & A_KMAJOR) or _f32(a_rowsum, "a_rowsum").numel() != M:
+            raise ValueError("gemm: a_rowsum needs a [K][M]-major A, no aux, and M elements")
+        epilogue |= EPI_A_ROWSUM
+        aux = a_rowsum
     nbytes = lib.dclip_gemm_f32_workspace(M, N, K, layout, split_k)
     ws = _ws.get(nbytes, a.device)
     _lib.check(lib.dclip_gemm_f32(a.data_ptr(), b.data_ptr(), out.data_ptr(), _ptr(bias), _ptr(residual),

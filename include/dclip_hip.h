@@ -64,6 +64,9 @@ const char* dclip_last_error(void);
  *   DGELU     v *= d/dx quick_gelu (aux[m,n])                          (its backward)
  *   RESIDUAL  v += residual[m,n]   (same ld as C)
  *   ACCUM     C[m,n] += v  instead of  C[m,n] = v
+ *   A_ROWSUM  additionally aux[m] = sum_k A[m,k] (aux is float[M] here; [K][M]-major A only, not with GELU/DGELU):
+ *             with A = dy in the wgrad layout this is the nn.Linear BIAS gradient, read off the operand
+ *             fragments the weight-gradient GEMM feeds to the matrix cores anyway — dy is not read a second time.
  * split_k > 1 partitions K over split_k workgroups per tile; partial tiles go to `workspace`
  * (dclip_gemm_f32_workspace bytes) and are summed in fixed order by a second launch, so the
  * result is run-to-run deterministic.  split_k == 0 lets the library choose.
@@ -76,6 +79,7 @@ const char* dclip_last_error(void);
 #define DCLIP_EPI_DGELU 4
 #define DCLIP_EPI_RESIDUAL 8
 #define DCLIP_EPI_ACCUM 16
+#define DCLIP_EPI_A_ROWSUM 32
 
 size_t dclip_gemm_f32_workspace(int M, int N, int K, int layout, int split_k);
 int dclip_gemm_f32(const float* A, const float* B, float* C, const float* bias, const float* residual,

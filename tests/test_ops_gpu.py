@@ -300,3 +300,23 @@ def test_fused_adamw_and_clip_match_torch(dev):
         assert abs(float(my_opt.last_grad_norm) - float(norm)) < 1e-5 * float(norm)
     for p, q in zip(ps, mine):
         assert relerr(q, p) < 1e-5 or float((q.cpu() - p).abs().max()) < 1e-7
+
+
+@pytest.mark.parametrize("M,N,K,split", [(768, 768, 12800, 0), (3072, 768, 12800, 0), (2304, 768, 12800, 4), (132, 64, 77, 1),
+                                         (768, 3072, 256, 0), (100, 36, 1000, 3)])
+def test_gemm_wgrad_rowsum_is_the_bias_gradient(M, N, K, split):
+    """DCLIP_EPI_A_ROWSUM: aux[m] = sum_k A[m,k] from the weight-gradient GEMM's own operand fragments."""
+    from dclip_amd import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(M + N + K)
+    dy = torch.randn(K, M, generator=g).to(dev)            # [rows, out]  = A as [K][M]
+    x = torch.randn(K, N, generator=g).to(dev)             # [rows, in]
+    db = torch.full((M,), float("nan"), device=dev)
+    dw = ops.gemm(dy, x, ops.LAYOUT_TN, a_rowsum=db, split_k=split)
+    ref_w = dy.double().t() @ x.double()
+    ref_b = dy.double().sum(0)
+    assert float((dw.double() - ref_w).abs().max() / ref_w.abs().max()) < 1e-5
+    assert float((db.double() - ref_b).abs().max() / ref_b.abs().max()) < 1e-5
+    assert torch.equal(dw, ops.gemm(dy, x, ops.LAYOUT_TN, split_k=split))        # the product itself is unchanged
+    with pytest.raises(ValueError):
+        ops.gemm(dy.t().contiguous(), x, ops.LAYOUT_NN, a_rowsum=db)

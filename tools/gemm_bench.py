@@ -7,11 +7,14 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--tile", default=None)
 ap.add_argument("--iters", type=int, default=20)
 ap.add_argument("--shapes", default="step")
+ap.add_argument("--lib", default=None, help="alternative libdclip_hip.so (A/B runs)")
 args = ap.parse_args()
 if args.tile:
     os.environ["DCLIP_GEMM_TILE"] = args.tile
 import torch
-from dclip_amd import ops
+from dclip_amd import ops, _lib
+if args.lib:
+    _lib.LIB_PATH = os.path.abspath(args.lib)
 
 dev = torch.device("cuda:0")
 M = 12800
