@@ -14,6 +14,7 @@
 // Probability-like tiles go from the accumulator layout (col on the lane) back to an A operand through a
 // per-wave [16][68] LDS scratch.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -221,6 +222,107 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(AttnArgs a, float* __rest
       for (int nt = 0; nt < 4; ++nt) out[((size_t)b * Sq + row) * D + h * HD + nt * 16 + l15] = o[nt][r] * inv;
       if (l15 == 0) lse[(size_t)bh * Sq + row] = m[r] + __logf(l[r]);
     }
+  }
+}
+
+// ------------------------------------------------------------------------------------------- forward, whole rows
+// Short self-attention (Sq == Sk <= 16*KT, KT <= 5: the 50-token ViT-B/32 and the 77-token text sequences): one
+// workgroup per (batch, head), one wave per 16 query rows, the whole K and V of the head in LDS once.
+//   * scores are produced TRANSPOSED (S^T = K Q^T): lane (l15, qd) then holds, for ITS query l15, the keys
+//     16kt + 4qd + r — exactly the B operand P^T[key][query] of O^T = V^T P^T when MFMA step r contracts over the
+//     keys {4qd + r}.  The contraction order of a dot product is free, so P never leaves the registers (no LDS
+//     round trip, no online rescaling: the whole row is there), and O^T comes out with 4 consecutive head
+//     dimensions per lane: 16-byte stores.
+//   * 16-row granularity: a causal wave w touches key tiles 0..w only (77 tokens: 15 of the 25 16x16 tiles).
+template <int KT, bool CAUSAL>
+__global__ void __launch_bounds__(KT * 64) attn_fwd_rows_kernel(AttnArgs a, float* __restrict__ out,
+                                                                float* __restrict__ lse) {
+  constexpr int R = KT * 16;
+  extern __shared__ __attribute__((aligned(16))) float lds_rows[];
+  float* Ks = lds_rows;
+  float* Vs = lds_rows + R * HD;
+  const int H = a.H, S = a.Sk;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int qd = lane >> 4, l15 = lane & 15;
+  const int bh = blockIdx.x, b = bh / H, h = bh % H;
+  const int D = H * HD;
+  const int query = 16 * wave + l15;
+  // Q never goes through LDS: a lane's B-operand fragments are 16-byte pieces of its own query row
+  f32x4 qf[4];
+  {
+    const float* qrow = a.q + ((size_t)b * S + min(query, S - 1)) * a.ldq + h * HD + 4 * qd;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) qf[g] = *reinterpret_cast<const f32x4*>(qrow + 16 * g);   // rows >= S: never stored
+  }
+  const float* src[2] = {a.k + (size_t)b * S * a.ldkv + h * HD, a.v + (size_t)b * S * a.ldkv + h * HD};
+#pragma unroll
+  for (int w = 0; w < 2; ++w) {
+    float* tile = lds_rows + w * R * HD;
+    for (int id = threadIdx.x; id < R * 16; id += KT * 64) {
+      const int row = id >> 4, slot = id & 15;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (row < S) v = *reinterpret_cast<const f32x4*>(src[w] + (size_t)row * a.ldkv + slot * 4);
+      *reinterpret_cast<f32x4*>(tile + row * HD + ((slot ^ (row & 15)) << 2)) = v;
+    }
+  }
+  __syncthreads();
+  const int nkt = CAUSAL ? wave + 1 : (S + 15) / 16;  // wave-uniform
+  f32x4 st[KT];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int kt = 0; kt < KT; ++kt) {
+    st[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (kt < nkt) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 kf = frag_k(Ks, 16 * kt, g, lane);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) st[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[r], qf[g][r], st[kt], 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = 16 * kt + 4 * qd + r;
+        float v = st[kt][r] * kScale;
+        if (key >= S || (CAUSAL && key > query)) v = -INFINITY;
+        st[kt][r] = v;
+        mx = fmaxf(mx, v);
+      }
+    }
+  }
+  mx = fmaxf(mx, __shfl_xor(mx, 16));
+  mx = fmaxf(mx, __shfl_xor(mx, 32));
+  float sum = 0.f;
+#pragma unroll
+  for (int kt = 0; kt < KT; ++kt)
+    if (kt < nkt) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float p = __expf(st[kt][r] - mx);
+        st[kt][r] = p;
+        sum += p;
+      }
+    }
+  sum += __shfl_xor(sum, 16);
+  sum += __shfl_xor(sum, 32);
+  f32x4 o[4];
+  zero4(o);
+#pragma unroll
+  for (int kt = 0; kt < KT; ++kt)
+    if (kt < nkt) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = 16 * kt + 4 * qd + r;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+          o[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(Vs[tile_off(key, 16 * dt + l15)], st[kt][r], o[dt], 0, 0, 0);
+      }
+    }
+  if (query < S) {
+    const float inv = 1.0f / sum;
+    float* orow = out + ((size_t)b * S + query) * D + h * HD + 4 * qd;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) *reinterpret_cast<f32x4*>(orow + 16 * dt) = o[dt] * inv;
+    if (qd == 0) lse[(size_t)bh * S + query] = mx + __logf(sum);
   }
 }
 
@@ -501,7 +603,25 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_fused_kernel(AttnArgs a, cons
 
 namespace {
 
+template <int KT>
+void launch_fwd_rows(const AttnArgs& a, float* out, float* lse, int B, int causal, hipStream_t st) {
+  const size_t lds = (size_t)2 * KT * 16 * HD * sizeof(float);
+  if (causal) hipLaunchKernelGGL((attn_fwd_rows_kernel<KT, true>), dim3(B * a.H), dim3(KT * 64), lds, st, a, out, lse);
+  else hipLaunchKernelGGL((attn_fwd_rows_kernel<KT, false>), dim3(B * a.H), dim3(KT * 64), lds, st, a, out, lse);
+}
+
 int launch_fwd(const AttnArgs& a, float* out, float* lse, int B, int causal, hipStream_t st) {
+  if (a.Sq == a.Sk && a.Sk <= 80 && !a.q_rows && !getenv("DCLIP_ATTN_TILED")) {   // whole-row kernel (see above)
+    switch (cdiv(a.Sk, 16)) {
+      case 1: launch_fwd_rows<1>(a, out, lse, B, causal, st); break;
+      case 2: launch_fwd_rows<2>(a, out, lse, B, causal, st); break;
+      case 3: launch_fwd_rows<3>(a, out, lse, B, causal, st); break;
+      case 4: launch_fwd_rows<4>(a, out, lse, B, causal, st); break;
+      default: launch_fwd_rows<5>(a, out, lse, B, causal, st); break;
+    }
+    DCLIP_CHECK_LAUNCH("attention_fwd.rows");
+    return DCLIP_OK;
+  }
   dim3 grid(B * a.H, cdiv(a.Sq, TS)), block(256);
   if (causal) hipLaunchKernelGGL((attn_fwd_kernel<true>), grid, block, 0, st, a, out, lse);
   else hipLaunchKernelGGL((attn_fwd_kernel<false>), grid, block, 0, st, a, out, lse);
