@@ -599,6 +599,169 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_fused_kernel(AttnArgs a, cons
   }
 }
 
+// ------------------------------------------------------------------------------------------- backward, whole rows
+// Short self-attention (S <= 16*KT): one workgroup per (batch, head), wave w owns rows 16w..16w+15 both as QUERIES
+// (phase 1 -> dQ) and as KEYS (phase 2 -> dK, dV).  Each phase forms the score / dP blocks it needs directly in the
+// register layout its products consume (see attn_fwd_rows_kernel: the contraction order is free), so P and dS never
+// touch LDS, there is no barrier after the staging one, and dQ / dK / dV leave as 16-byte stores.  The price is
+// forming S and dP twice (7 MFMA products instead of 5); the LDS operand traffic drops by a third.
+template <int KT, bool CAUSAL>
+__global__ void __launch_bounds__(KT * 64) attn_bwd_rows_kernel(AttnArgs a, const float* __restrict__ out,
+                                                                const float* __restrict__ dout,
+                                                                const float* __restrict__ lse, float* __restrict__ dq_out,
+                                                                float* __restrict__ dk_out, float* __restrict__ dv_out,
+                                                                int ldd) {
+  constexpr int R = KT * 16;
+  __shared__ __attribute__((aligned(16))) float lds[4 * R * HD + 2 * R];
+  float* Qs = lds;
+  float* Ks = lds + R * HD;
+  float* Vs = lds + 2 * R * HD;
+  float* dOs = lds + 3 * R * HD;
+  float* lse_s = lds + 4 * R * HD;
+  float* dl_s = lse_s + R;
+  const int H = a.H, S = a.Sk;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int qd = lane >> 4, l15 = lane & 15;
+  const int bh = blockIdx.x, b = bh / H, h = bh % H;
+  const int D = H * HD;
+  const float* src[4] = {a.q + (size_t)b * S * a.ldq + h * HD, a.k + (size_t)b * S * a.ldkv + h * HD,
+                         a.v + (size_t)b * S * a.ldkv + h * HD, dout + (size_t)b * S * D + h * HD};
+  const size_t lds_[4] = {(size_t)a.ldq, (size_t)a.ldkv, (size_t)a.ldkv, (size_t)D};
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    float* tile = lds + w * R * HD;
+    for (int id = threadIdx.x; id < R * 16; id += KT * 64) {
+      const int row = id >> 4, slot = id & 15;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (row < S) v = *reinterpret_cast<const f32x4*>(src[w] + (size_t)row * lds_[w] + slot * 4);
+      *reinterpret_cast<f32x4*>(tile + row * HD + ((slot ^ (row & 15)) << 2)) = v;
+    }
+  }
+  // delta = rowsum(O * dO) and lse of this wave's rows: lane (l15, qd) covers 16 of the 64 head dims of row 16w + l15
+  const int own = 16 * wave + l15;
+  float my_lse = 0.f, my_dl = 0.f;
+  if (own < S) {
+    const float* orow = out + ((size_t)b * S + own) * D + h * HD + 4 * qd;
+    const float* drow = dout + ((size_t)b * S + own) * D + h * HD + 4 * qd;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 o4 = *reinterpret_cast<const f32x4*>(orow + 16 * g);
+      const f32x4 d4 = *reinterpret_cast<const f32x4*>(drow + 16 * g);
+      my_dl += (o4[0] * d4[0] + o4[1] * d4[1]) + (o4[2] * d4[2] + o4[3] * d4[3]);
+    }
+    my_lse = lse[(size_t)bh * S + own];
+  }
+  my_dl += __shfl_xor(my_dl, 16);
+  my_dl += __shfl_xor(my_dl, 32);
+  if (qd == 0) {
+    lse_s[own] = my_lse;
+    dl_s[own] = my_dl;
+  }
+  __syncthreads();
+  const int kts = (S + 15) / 16;  // 16-row tiles that hold data
+
+  // ---- phase 1: own queries (lane column l15), every key tile -> dQ
+  {
+    f32x4 qf[4], dof[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      qf[g] = frag_k(Qs, 16 * wave, g, lane);
+      dof[g] = frag_k(dOs, 16 * wave, g, lane);
+    }
+    f32x4 dq[4];
+    zero4(dq);
+    const int n1 = CAUSAL ? min(kts, wave + 1) : kts;
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt)
+      if (kt < n1) {
+        f32x4 st = {0.f, 0.f, 0.f, 0.f}, dpt = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 kf = frag_k(Ks, 16 * kt, g, lane);
+          const f32x4 vf = frag_k(Vs, 16 * kt, g, lane);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            st = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[r], qf[g][r], st, 0, 0, 0);
+            dpt = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[r], dof[g][r], dpt, 0, 0, 0);
+          }
+        }
+        f32x4 ds;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = 16 * kt + 4 * qd + r;
+          const bool masked = key >= S || (CAUSAL && key > own);
+          const float pr = masked ? 0.f : __expf(st[r] * kScale - my_lse);
+          ds[r] = pr * (dpt[r] - my_dl) * kScale;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = 16 * kt + 4 * qd + r;
+#pragma unroll
+          for (int dt = 0; dt < 4; ++dt)
+            dq[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(Ks[tile_off(key, 16 * dt + l15)], ds[r], dq[dt], 0, 0, 0);
+        }
+      }
+    if (own < S) {
+      float* o = dq_out + ((size_t)b * S + own) * ldd + h * HD + 4 * qd;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) *reinterpret_cast<f32x4*>(o + 16 * dt) = dq[dt];
+    }
+  }
+
+  // ---- phase 2: own keys (lane column l15), every query tile -> dK, dV
+  {
+    f32x4 kf[4], vf[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      kf[g] = frag_k(Ks, 16 * wave, g, lane);
+      vf[g] = frag_k(Vs, 16 * wave, g, lane);
+    }
+    f32x4 dk[4], dv[4];
+    zero4(dk);
+    zero4(dv);
+#pragma unroll
+    for (int qt = 0; qt < KT; ++qt)
+      if (qt < kts && (!CAUSAL || qt >= wave)) {
+        f32x4 s2 = {0.f, 0.f, 0.f, 0.f}, dp2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 qf = frag_k(Qs, 16 * qt, g, lane);
+          const f32x4 df = frag_k(dOs, 16 * qt, g, lane);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            s2 = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[r], kf[g][r], s2, 0, 0, 0);
+            dp2 = __builtin_amdgcn_mfma_f32_16x16x4f32(df[r], vf[g][r], dp2, 0, 0, 0);
+          }
+        }
+        f32x4 pr, ds;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int q = 16 * qt + 4 * qd + r;
+          const bool masked = q >= S || own >= S || (CAUSAL && own > q);
+          pr[r] = masked ? 0.f : __expf(s2[r] * kScale - lse_s[q]);
+          ds[r] = pr[r] * (dp2[r] - dl_s[q]) * kScale;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int q = 16 * qt + 4 * qd + r;
+#pragma unroll
+          for (int dt = 0; dt < 4; ++dt) {
+            dv[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(dOs[tile_off(q, 16 * dt + l15)], pr[r], dv[dt], 0, 0, 0);
+            dk[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(Qs[tile_off(q, 16 * dt + l15)], ds[r], dk[dt], 0, 0, 0);
+          }
+        }
+      }
+    if (own < S) {
+      const size_t o = ((size_t)b * S + own) * ldd + h * HD + 4 * qd;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        *reinterpret_cast<f32x4*>(dk_out + o + 16 * dt) = dk[dt];
+        *reinterpret_cast<f32x4*>(dv_out + o + 16 * dt) = dv[dt];
+      }
+    }
+  }
+}
+
 }  // namespace
 
 namespace {
@@ -632,6 +795,16 @@ int launch_fwd(const AttnArgs& a, float* out, float* lse, int B, int causal, hip
 int launch_bwd(const AttnArgs& a, const float* out, const float* dout, const float* lse, float* dq, int lddq, float* dk,
                float* dv, int lddkv, float* delta, int B, int causal, hipStream_t st) {
   dim3 gq(B * a.H, cdiv(a.Sq, TS)), gk(B * a.H, cdiv(a.Sk, TS)), block(256);
+  if (a.Sq == a.Sk && a.Sk > TS && a.Sk <= 80 && lddq == lddkv && !getenv("DCLIP_ATTN_TILED")) {
+    // 65..80 rows (the 77-token text tower when it trains): whole-row kernel, 5 waves.  Measured 214 us vs 362 us for
+    // the two-kernel tiled path at B=256, H=8; for S <= 64 the 5-product one-tile kernel below is faster (154 vs 178).
+    if (causal)
+      hipLaunchKernelGGL((attn_bwd_rows_kernel<5, true>), dim3(B * a.H), dim3(320), 0, st, a, out, dout, lse, dq, dk, dv, lddq);
+    else
+      hipLaunchKernelGGL((attn_bwd_rows_kernel<5, false>), dim3(B * a.H), dim3(320), 0, st, a, out, dout, lse, dq, dk, dv, lddq);
+    DCLIP_CHECK_LAUNCH("attention_bwd.rows");
+    return DCLIP_OK;
+  }
   if (a.Sq == a.Sk && a.Sq <= TS && lddq == lddkv) {  // one-tile self-attention: fused dQ/dK/dV
     if (causal) hipLaunchKernelGGL((attn_bwd_fused_kernel<true>), dim3(B * a.H), block, 0, st, a, out, dout, lse, dq, dk, dv, lddq);
     else hipLaunchKernelGGL((attn_bwd_fused_kernel<false>), dim3(B * a.H), block, 0, st, a, out, dout, lse, dq, dk, dv, lddq);

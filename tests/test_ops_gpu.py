@@ -154,7 +154,9 @@ def ref_attention(qkv, B, S, H, causal):
 
 
 @pytest.mark.parametrize("B,S,H,causal", [(2, 50, 2, False), (3, 77, 2, True), (1, 197, 3, False), (2, 10, 1, True),
-                                          (1, 257, 2, False), (2, 16, 2, True), (1, 64, 1, False), (1, 130, 1, True)])
+                                          (1, 257, 2, False), (2, 16, 2, True), (1, 64, 1, False), (1, 130, 1, True),
+                                          (2, 65, 2, True), (2, 80, 1, False), (2, 77, 2, False), (1, 81, 1, True),
+                                          (2, 1, 1, True), (2, 33, 2, False), (1, 48, 1, True)])
 def test_attention_fwd_bwd(dev, B, S, H, causal):
     from dclip_amd import ops
     qkv = rnd((B * S, 3 * H * 64), 1, 1.5)

@@ -33,3 +33,20 @@ for name, B, S, H, causal in [("vision B/32", 256, 50, 12, False), ("text", 256,
         err = float((o1 - o2).abs().max()), float((l1 - l2).abs().max())
         mb = (4 * B * S * H * 64 * 4) / 1e6
         print(f"{name}: rows {a:.1f} us ({mb / a * 1e3 / 1e3:.2f} TB/s) | tiled {b:.1f} us | max diff out {err[0]:.2e} lse {err[1]:.2e}", flush=True)
+
+print("--- backward")
+for name, B, S, H, causal in [("vision B/32", 256, 50, 12, False), ("text", 256, 77, 8, True), ("tiny", 8, 17, 2, True)]:
+    qkv = torch.randn(B * S, 3 * H * 64, device=dev)
+    os.environ.pop("DCLIP_ATTN_TILED", None)
+    o, l = ops.attention_fwd(qkv, B, S, H, causal)
+    do = torch.randn_like(o)
+    for rep in range(2):
+        os.environ.pop("DCLIP_ATTN_TILED", None)
+        a = t(lambda: ops.attention_bwd(qkv, o, do, l, B, S, H, causal))
+        g1 = ops.attention_bwd(qkv, o, do, l, B, S, H, causal)
+        os.environ["DCLIP_ATTN_TILED"] = "1"
+        b = t(lambda: ops.attention_bwd(qkv, o, do, l, B, S, H, causal))
+        g2 = ops.attention_bwd(qkv, o, do, l, B, S, H, causal)
+        err = float((g1 - g2).abs().max() / g2.abs().max())
+        mb = (8 * B * S * H * 64 * 4) / 1e6
+        print(f"{name}: rows {a:.1f} us ({mb / a / 1e3:.2f} TB/s) | previous {b:.1f} us | max rel diff {err:.2e}", flush=True)
