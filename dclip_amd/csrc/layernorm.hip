@@ -125,23 +125,34 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const float* __restrict__ d
   }
 }
 
-// out[n] (+)= sum_p partial[p][n]   (fixed order -> deterministic).  Block = 64 columns x 16 row groups.
+// out[n] (+)= sum_p partial[p][n]   (fixed order -> deterministic).  Block = 16 columns x 64 row groups: N/16
+// workgroups (96 for the 2 x 768 LayerNorm partials) instead of N/64, each thread adds P/64 values — the partials
+// are L2 / Infinity-Cache resident (just written), so this is latency, not bandwidth: width buys time.
+constexpr int RP_COLS = 16, RP_GROUPS = 64;
 __global__ void __launch_bounds__(1024) reduce_partials_kernel(const float* __restrict__ partial, float* __restrict__ out0,
                                                                float* __restrict__ out1, int P, int N0, int N1,
                                                                int accumulate) {
-  __shared__ float red[16][64];
-  const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
-  const int n = blockIdx.x * 64 + cl;
+  __shared__ float red[RP_GROUPS][RP_COLS + 1];
+  __shared__ float red2[4][RP_COLS];
+  const int cl = threadIdx.x % RP_COLS, rg = threadIdx.x / RP_COLS;
+  const int n = blockIdx.x * RP_COLS + cl;
   const int N = N0 + N1;
   float s = 0.f;
   if (n < N)
-    for (int p = rg; p < P; p += 16) s += partial[(size_t)p * N + n];
+    for (int p = rg; p < P; p += RP_GROUPS) s += partial[(size_t)p * N + n];
   red[rg][cl] = s;
   __syncthreads();
-  if (rg != 0 || n >= N) return;
-  s = 0.f;
+  // 64 -> 4 partial sums per column by 64 threads, then the last 4 by 16: always the same association
+  if (threadIdx.x < RP_COLS * 4) {
+    const int c = threadIdx.x % RP_COLS, q = threadIdx.x / RP_COLS;
+    float t = 0.f;
 #pragma unroll
-  for (int k = 0; k < 16; ++k) s += red[k][cl];
+    for (int k = 0; k < 16; ++k) t += red[q * 16 + k][c];
+    red2[q][c] = t;
+  }
+  __syncthreads();
+  if (threadIdx.x >= RP_COLS || n >= N) return;
+  s = (red2[0][cl] + red2[1][cl]) + (red2[2][cl] + red2[3][cl]);
   float* base = (n < N0) ? out0 : out1;
   if (!base) return;
   float* o = base + ((n < N0) ? n : n - N0);
@@ -230,7 +241,7 @@ DCLIP_API int dclip_layernorm_bwd(const float* dy, const float* x, const float* 
 #undef LN_BWD
   DCLIP_CHECK_LAUNCH("layernorm_bwd");
   if (want_params) {
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(2 * D, 64)), dim3(1024), 0, st, partial, dgamma, dbeta, blocks, D,
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(2 * D, RP_COLS)), dim3(1024), 0, st, partial, dgamma, dbeta, blocks, D,
                        D, accumulate_param_grads);
     DCLIP_CHECK_LAUNCH("layernorm_bwd.reduce");
   }
@@ -251,7 +262,7 @@ DCLIP_API int dclip_colsum_f32(const float* X, float* out, int M, int N, int ldx
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(N / 4, 64), splits), dim3(256), 0, st, X, (float*)workspace, M, N, ldx);
   DCLIP_CHECK_LAUNCH("colsum");
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(N, 64)), dim3(1024), 0, st, (const float*)workspace, out,
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(N, RP_COLS)), dim3(1024), 0, st, (const float*)workspace, out,
                      (float*)nullptr, splits, N, 0, accumulate);
   DCLIP_CHECK_LAUNCH("colsum.reduce");
   return DCLIP_OK;
