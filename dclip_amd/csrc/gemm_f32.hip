@@ -71,12 +71,13 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 }
 
 template <int BM, int BN, int WM, int WN, bool A_KMAJOR, bool B_KMAJOR>
-__global__ void __launch_bounds__(256, 2) gemm_f32_kernel(GemmParams p) {
+__global__ void __launch_bounds__(WM * WN * 64, 2) gemm_f32_kernel(GemmParams p) {
+  constexpr int NTHR = WM * WN * 64;  // 4 waves, or 8 for the 128x128 tile (two 64x32 wave tiles per SIMD)
   constexpr int TM = BM / WM, TN = BN / WN;
   constexpr int MT = TM / 32, NT = TN / 32;
-  constexpr int A_CHUNKS = BM * BK / 4 / 256;  // 16-byte chunks per thread per K-tile
-  constexpr int B_CHUNKS = BN * BK / 4 / 256;
-  static_assert(WM * WN == 4, "4 waves");
+  constexpr int A_CHUNKS = BM * BK / 4 / NTHR;  // 16-byte chunks per thread per K-tile
+  constexpr int B_CHUNKS = BN * BK / 4 / NTHR;
+  static_assert(WM * WN == 4 || WM * WN == 8, "4 or 8 waves");
   static_assert(A_CHUNKS >= 1 && B_CHUNKS >= 1, "tile too small");
 
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -114,7 +115,7 @@ __global__ void __launch_bounds__(256, 2) gemm_f32_kernel(GemmParams p) {
   // DCLIP_EPI_A_ROWSUM: sum_k A[m][k] is accumulated from the staged chunks of a [K][M]-major A while they sit in
   // registers (every chunk of a thread covers the same 4 columns m: 256 % (BM/4) == 0); the workgroups of tile
   // column 0 reduce across threads through LDS after the K loop and store.
-  static_assert(256 % (BM / 4) == 0, "a thread's A chunks must share their m columns");
+  static_assert(NTHR % (BM / 4) == 0, "a thread's A chunks must share their m columns");
   const bool do_rs = !A_KMAJOR && (p.epilogue & DCLIP_EPI_A_ROWSUM) && tile_n == 0;   // workgroup-uniform
   f32x4 rs4 = {0.f, 0.f, 0.f, 0.f};
 
@@ -143,13 +144,13 @@ __global__ void __launch_bounds__(256, 2) gemm_f32_kernel(GemmParams p) {
   int a_voff[A_CHUNKS], b_voff[B_CHUNKS];
 #pragma unroll
   for (int c = 0; c < A_CHUNKS; ++c) {
-    const int id = tid + c * 256;
+    const int id = tid + c * NTHR;
     if (A_KMAJOR) a_voff[c] = (min(id >> 3, a_rows - 1) * p.lda + (id & 7) * 4) * 4;
     else a_voff[c] = ((id / (BM / 4)) * p.lda + min((id % (BM / 4)) * 4, p.M - m0 - 4)) * 4;
   }
 #pragma unroll
   for (int c = 0; c < B_CHUNKS; ++c) {
-    const int id = tid + c * 256;
+    const int id = tid + c * NTHR;
     if (B_KMAJOR) b_voff[c] = (min(id >> 3, b_rows - 1) * p.ldb + (id & 7) * 4) * 4;
     else b_voff[c] = ((id / (BN / 4)) * p.ldb + min((id % (BN / 4)) * 4, p.N - n0 - 4)) * 4;
   }
@@ -170,7 +171,7 @@ __global__ void __launch_bounds__(256, 2) gemm_f32_kernel(GemmParams p) {
     const int krem = kspan - kt * BK;  // valid k in this tile (>= BK unless ragged)
 #pragma unroll
     for (int c = 0; c < A_CHUNKS; ++c) {
-      const int id = tid + c * 256;
+      const int id = tid + c * NTHR;
       f32x4 v = ra[c];
       if (A_KMAJOR) {
         const int row = id >> 3, slot = id & 7;
@@ -186,7 +187,7 @@ __global__ void __launch_bounds__(256, 2) gemm_f32_kernel(GemmParams p) {
     }
 #pragma unroll
     for (int c = 0; c < B_CHUNKS; ++c) {
-      const int id = tid + c * 256;
+      const int id = tid + c * NTHR;
       f32x4 v = rb[c];
       if (B_KMAJOR) {
         const int row = id >> 3, slot = id & 7;
@@ -246,7 +247,7 @@ __global__ void __launch_bounds__(256, 2) gemm_f32_kernel(GemmParams p) {
   // unmasked registers -> LDS for ONE staged chunk (A chunks first, then B chunks)
   auto store_chunk = [&](int buf, int c) {
     if (c < A_CHUNKS) {
-      const int id = tid + c * 256;
+      const int id = tid + c * NTHR;
       float* a = As + buf * BM * BK;
       if (A_KMAJOR) {
         const int row = id >> 3, slot = id & 7;
@@ -256,7 +257,7 @@ __global__ void __launch_bounds__(256, 2) gemm_f32_kernel(GemmParams p) {
       }
     } else {
       const int cb = c - A_CHUNKS;
-      const int id = tid + cb * 256;
+      const int id = tid + cb * NTHR;
       float* b = Bs + buf * BN * BK;
       if (B_KMAJOR) {
         const int row = id >> 3, slot = id & 7;
@@ -336,7 +337,7 @@ __global__ void __launch_bounds__(256, 2) gemm_f32_kernel(GemmParams p) {
       constexpr int MC = BM / 4;  // m-chunks per K row; thread t holds chunk t % MC
       float t = 0.f;
 #pragma unroll
-      for (int kr = 0; kr < 256 / MC; ++kr) t += lds[(kr * MC + tid / 4) * 4 + (tid & 3)];
+      for (int kr = 0; kr < NTHR / MC; ++kr) t += lds[(kr * MC + tid / 4) * 4 + (tid & 3)];
       if (p.slab) p.rs_slab[(size_t)blockIdx.y * p.M + m0 + tid] = t;
       else p.aux[m0 + tid] = t;
     }
@@ -431,21 +432,21 @@ __global__ void __launch_bounds__(256, 2) gemm_f32_kernel(GemmParams p) {
         for (int r = 0; r < 16; ++r)
           ct[(wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * BN + wn * TN + j * 32 + l31] = acc[i][j][r];
     __syncthreads();
-    constexpr int CHUNKS = BM * BN / 4 / 256;
+    constexpr int CHUNKS = BM * BN / 4 / NTHR;
     const float* s0 = (epi & DCLIP_EPI_DGELU) ? p.aux : p.residual;
     const bool has_s0 = epi & (DCLIP_EPI_RESIDUAL | DCLIP_EPI_DGELU);
     f32x4 side[CHUNKS];
     if (has_s0) {
 #pragma unroll
       for (int q = 0; q < CHUNKS; ++q) {
-        const int id = tid + q * 256;
+        const int id = tid + q * NTHR;
         const int row = m0 + id / (BN / 4), col = n0 + (id % (BN / 4)) * 4;
         side[q] = *reinterpret_cast<const f32x4*>(s0 + (size_t)row * p.ldc + col);
       }
     }
 #pragma unroll
     for (int q = 0; q < CHUNKS; ++q) {
-      const int id = tid + q * 256;
+      const int id = tid + q * NTHR;
       const int lr = id / (BN / 4), lc = (id % (BN / 4)) * 4;
       const int row = m0 + lr, col = n0 + lc;
       f32x4 v = *reinterpret_cast<const f32x4*>(ct + lr * BN + lc);
@@ -557,13 +558,13 @@ int launch_cfg(const GemmParams& p, int layout, int splits, hipStream_t st) {
   const size_t lds = (size_t)2 * (BM + BN) * BK * sizeof(float);
   const bool ak = layout & DCLIP_A_KMAJOR, bk = layout & DCLIP_B_KMAJOR;
   if (ak && bk)
-    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, true, true>), grid, dim3(256), lds, st, p);
+    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, true, true>), grid, dim3(WM * WN * 64), lds, st, p);
   else if (ak && !bk)
-    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, true, false>), grid, dim3(256), lds, st, p);
+    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, true, false>), grid, dim3(WM * WN * 64), lds, st, p);
   else if (!ak && bk)
-    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, false, true>), grid, dim3(256), lds, st, p);
+    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, false, true>), grid, dim3(WM * WN * 64), lds, st, p);
   else
-    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, false, false>), grid, dim3(256), lds, st, p);
+    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, false, false>), grid, dim3(WM * WN * 64), lds, st, p);
   return 0;
 }
 
@@ -661,7 +662,9 @@ DCLIP_API int dclip_gemm_f32(const float* A, const float* B, float* C, const flo
     p.rs_slab = p.slab + (size_t)pl.splits * M * N;
   }
   hipStream_t st = (hipStream_t)stream;
-  if (pl.bm == 128 && pl.bn == 128) launch_cfg<128, 128, 2, 2>(p, layout, pl.splits, st);
+  static const bool w8 = getenv("DCLIP_GEMM_W8") != nullptr;   // experiment: 8-wave 128x128 workgroups
+  if (pl.bm == 128 && pl.bn == 128 && w8) launch_cfg<128, 128, 2, 4>(p, layout, pl.splits, st);
+  else if (pl.bm == 128 && pl.bn == 128) launch_cfg<128, 128, 2, 2>(p, layout, pl.splits, st);
   else if (pl.bm == 128 && pl.bn == 64) launch_cfg<128, 64, 2, 2>(p, layout, pl.splits, st);
   else if (pl.bm == 64 && pl.bn == 128) launch_cfg<64, 128, 2, 2>(p, layout, pl.splits, st);
   else launch_cfg<64, 64, 2, 2>(p, layout, pl.splits, st);
