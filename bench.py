@@ -138,6 +138,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-optimizer", action="store_true", help="time forward+backward only")
     ap.add_argument("--no-gemm-events", action="store_true", help="do not bracket GEMM launches with HIP events")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay forward+backward from a captured HIP graph (dclip_amd/graph.py; N=1 only).  Per-launch "
+                         "GEMM events do not exist inside a graph: `roofline` is then taken from an eager pass of the "
+                         "same step before the timed region")
     ap.add_argument("--workload", default="c2", choices=["c2", "c3"],
                     help="c2 (default, the benched config): teacher image embedding given.  c3: the meta-teacher runs "
                          "inside the step on --regions crops per image (separate frozen teacher CLIP of --teacher-model)")
@@ -209,7 +213,30 @@ def main():
     if not args.no_gemm_events:
         timer.install()
 
+    graphed = None
+    if args.graph:
+        if world > 1:
+            raise SystemExit("--graph captures a single-process step")
+        from dclip_amd.graph import GraphedStep
+        timer.enabled = True                     # eager pass: per-launch GEMM events for the roofline figure
+        for _ in range(2):
+            for p_ in trainable:
+                p_.grad = None
+            module.training_step(batch).backward()
+        torch.cuda.synchronize()
+        timer.enabled = False
+        eager_gemm = timer.summary()
+        eager_gemm = (eager_gemm[0] / 2, eager_gemm[1] / 2, eager_gemm[2] // 2)      # per step
+        for p_ in trainable:
+            p_.grad = None
+        graphed = GraphedStep(module, batch)
+
     def step():
+        if graphed is not None:
+            loss = graphed.step()                # inputs already sit in the captured buffers
+            if opt is not None:
+                opt.step()                       # gradients stay allocated in the graph's pool: no zero_grad
+            return loss
         loss = module.training_step(batch)      # N > 1: this rank's share of the global loss (dist.py)
         loss.backward()
         if sync is not None:
@@ -228,7 +255,7 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    timer.enabled = True
+    timer.enabled = graphed is None
     t0 = time.perf_counter()
     for _ in range(args.steps):
         last = step()
@@ -254,6 +281,8 @@ def main():
                                  + text_fwd_flops(tcfg.text, T) + 2.0 * T * tcfg.text.hidden_size * E
                                  + 8.0 * E * E * (T + R) + 8.0 * T * R * E)
         gflops, gms, glaunches = timer.summary() if not args.no_gemm_events else (0.0, 0.0, 0)
+        if graphed is not None:                  # scale the eager per-step figures to the K timed steps
+            gflops, gms, glaunches = eager_gemm[0] * args.steps, eager_gemm[1] * args.steps, eager_gemm[2] * args.steps
         achieved = gflops / (gms * 1e-3) / 1e12 if gms > 0 else None
         if os.environ.get("DCLIP_BENCH_SHAPES") and not args.no_gemm_events:
             for (M_, N_, K_, lay), (n, ms, tf) in sorted(timer.by_shape().items(), key=lambda kv: -kv[1][1]):
@@ -283,7 +312,8 @@ def main():
                                     f"meta-teacher in the step ({args.regions} region crops/img through a frozen "
                                     f"{tcfg.name} tower with {args.tower_precision} GEMM inputs, token-level text, "
                                     f"cross-modal attention + aggregation), bs={B}/GPU, ")
-                                   + ("fwd+bwd only" if opt is None else "fwd+bwd + clip-norm 0.5 + AdamW"),
+                                   + ("fwd+bwd only" if opt is None else "fwd+bwd + clip-norm 0.5 + AdamW")
+                                   + (", fwd+bwd replayed from a HIP graph" if graphed is not None else ""),
                        "global_batch": world * B, "parallelism": f"dp{world}",
                        "loss": float(last.detach())},
             "roofline": {"bound": "mfma", "kernel": "gemm_f32_kernel (v_mfma_f32_32x32x2_f32)",

@@ -94,7 +94,11 @@ class Trainer:
     accumulate_grad_batches=4, callbacks=[ModelCheckpoint(...)]).fit(model)` — the subset the launcher uses."""
 
     def __init__(self, max_epochs: int = 1, gradient_clip_val: Optional[float] = 0.5, accumulate_grad_batches: int = 4,
-                 checkpoint_dir: Optional[str] = None, save_top_k: int = 10, max_steps: Optional[int] = None, **_ignored):
+                 checkpoint_dir: Optional[str] = None, save_top_k: int = 10, max_steps: Optional[int] = None,
+                 use_hip_graph: bool = False, **_ignored):
+        """`use_hip_graph`: replay forward+backward from a captured HIP graph (dclip_amd/graph.py) — tensor batches of
+        one fixed shape, single process; the update sequence and its results are those of the eager loop."""
+        self.use_hip_graph = use_hip_graph
         self.max_epochs = max_epochs
         self.clip = gradient_clip_val
         self.accum = max(1, accumulate_grad_batches)
@@ -111,22 +115,40 @@ class Trainer:
         val = val_dataloaders if val_dataloaders is not None else (
             model.val_dataloader() if hasattr(model, "val_dataloader") else None)
         step = 0
+        graphed, acc, gparams = None, None, None
         for epoch in range(self.max_epochs):
             model.current_epoch = epoch
             model.train()
-            opt.zero_grad(set_to_none=True)
+            if graphed is None:
+                opt.zero_grad(set_to_none=True)
             last = None
             for i, batch in enumerate(train):
-                loss = model.training_step(batch)
-                (loss / self.accum).backward()
-                last = loss.detach()
+                if self.use_hip_graph:
+                    if graphed is None:
+                        from .graph import GraphedStep
+                        graphed = GraphedStep(model, batch)
+                        gparams = [p for p in model.parameters() if p.requires_grad and p.grad is not None]
+                        if self.accum > 1:
+                            acc = [torch.zeros_like(p) for p in gparams]
+                    loss = graphed.step(batch)
+                    last = loss.detach().clone()
+                    if acc is not None:        # the graph ASSIGNS this micro-batch's gradients; accumulate by hand
+                        torch._foreach_add_(acc, [p.grad for p in gparams], alpha=1.0 / self.accum)
+                        if (i + 1) % self.accum == 0:
+                            torch._foreach_copy_([p.grad for p in gparams], acc)
+                            torch._foreach_zero_(acc)
+                else:
+                    loss = model.training_step(batch)
+                    (loss / self.accum).backward()
+                    last = loss.detach()
                 if (i + 1) % self.accum == 0:
                     if self.clip:
                         torch.nn.utils.clip_grad_norm_([p for p in model.parameters() if p.grad is not None], self.clip)
                     opt.step()
                     if sched is not None:
                         sched.step()
-                    opt.zero_grad(set_to_none=True)
+                    if graphed is None:            # graph mode: gradients live in the graph's pool and are overwritten
+                        opt.zero_grad(set_to_none=True)
                     step += 1
                     model.global_step = step
                 if self.max_steps is not None and step >= self.max_steps:

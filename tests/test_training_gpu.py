@@ -78,3 +78,68 @@ def test_student_launcher_trains_and_checkpoints(tmp_path):
     a = model.student.state_dict()["visual_projection.weight"].cpu()
     assert torch.equal(re.student.state_dict()["visual_projection.weight"].cpu(), a)
     assert model.logged("val_loss") > 0
+
+
+def test_graphed_step_replays_the_eager_step():
+    """hipGraph replay of forward + backward: same loss and gradients as the eager step, on new data each replay."""
+    import argparse
+    from dclip_amd import config as dcfg, synth
+    from dclip_amd.CLIP_image_distillation import CLIPImageDistillation
+    from dclip_amd.clip_model import from_hf_state_dict
+    from dclip_amd.graph import GraphedStep
+    dev = torch.device("cuda:0")
+    cfg = dcfg.tiny()
+    B = 6
+
+    def make():
+        student = from_hf_state_dict(cfg, synth.synth_clip_state_dict(cfg, seed=0), device=dev)
+        hp = argparse.Namespace(learning_rate=1e-4, warmup_steps=0, total_steps=100, train_batch_size=B, eval_batch_size=B)
+        return CLIPImageDistillation(hp, student, None, freeze_mode="north_star").to(dev)
+
+    def batch(seed):
+        return {"pixel_values": synth.synth_pixel_values(B, cfg.vision, seed=seed).to(dev),
+                "input_ids": synth.synth_input_ids(B, cfg.text, seed=seed + 1, ragged=True).to(dev),
+                "teacher_image_emb": synth.synth_embeddings(B, cfg.projection_dim, seed=seed + 2).to(dev)}
+
+    eager, graphed = make(), make()
+    g = GraphedStep(graphed, batch(10))
+    names = [n for n, p in eager.named_parameters() if p.requires_grad]
+    for seed in (20, 30, 40):
+        for p in eager.parameters():
+            p.grad = None
+        le = eager.training_step(batch(seed))
+        le.backward()
+        lg = g.step(batch(seed))
+        assert torch.equal(le.detach(), lg.detach()), (float(le), float(lg))
+        ge = dict(eager.named_parameters())
+        gg = dict(graphed.named_parameters())
+        for n in names:
+            assert torch.equal(ge[n].grad, gg[n].grad), n
+    with pytest.raises(ValueError):
+        g.step({"pixel_values": torch.zeros(2, 3, cfg.vision.image_size, cfg.vision.image_size, device=dev)})
+
+
+def test_trainer_with_hip_graph_matches_eager_trainer():
+    """Trainer(use_hip_graph=True) with gradient accumulation 2 and clipping: same parameters after 4 optimizer steps
+    as the eager Trainer (the only difference is the association of the accumulated sum: g1/2 + g2/2 either way)."""
+    from dclip_amd.CLIP_image_distillation import CLIPImageDistillation
+    from dclip_amd.clip_model import from_hf_state_dict
+    from dclip_amd.lightning_lite import Trainer
+    dev = torch.device("cuda:0")
+    cfg = dcfg.tiny()
+    B = 4
+
+    def run(use_graph):
+        student = from_hf_state_dict(cfg, synth.synth_clip_state_dict(cfg, seed=0), device=dev)
+        hp = argparse.Namespace(learning_rate=1e-3, warmup_steps=0, total_steps=100, train_batch_size=B, eval_batch_size=B)
+        m = CLIPImageDistillation(hp, student, None, freeze_mode="north_star").to(dev)
+        batches = [{"pixel_values": synth.synth_pixel_values(B, cfg.vision, seed=s),
+                    "input_ids": synth.synth_input_ids(B, cfg.text, seed=s + 1, ragged=True),
+                    "teacher_image_emb": synth.synth_embeddings(B, cfg.projection_dim, seed=s + 2)} for s in range(0, 80, 10)]
+        Trainer(max_epochs=1, gradient_clip_val=0.5, accumulate_grad_batches=2, use_hip_graph=use_graph).fit(m, batches)
+        return {n: p.detach().clone() for n, p in m.named_parameters() if p.requires_grad}
+
+    a, b = run(False), run(True)
+    assert a.keys() == b.keys()
+    for n in a:
+        assert torch.allclose(a[n], b[n], rtol=1e-5, atol=1e-7), (n, float((a[n] - b[n]).abs().max()))
