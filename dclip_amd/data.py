@@ -179,7 +179,7 @@ class ClipImagePreprocess:
         """PIL image / HWC uint8 array -> HWC uint8 RGB array."""
         if hasattr(image, "convert"):
             image = image.convert("RGB")
-        arr = np.asarray(image, dtype=np.uint8)
+        arr = np.array(image, dtype=np.uint8)          # a writable copy (torch.from_numpy wants one)
         if arr.ndim != 3 or arr.shape[2] != 3:
             raise ValueError(f"expected an RGB image, got array of shape {arr.shape}")
         return arr

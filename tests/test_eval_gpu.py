@@ -66,3 +66,64 @@ def test_evaluate_zero_shot_end_to_end():
     labels = [torch.randint(0, 10, (6,)) for _ in range(2)]
     res = E.evaluate_zero_shot(m, imgs, labels, synth.synth_input_ids(10, cfg.text, seed=2, ragged=True))
     assert 0.0 <= res["top1"] <= res["top5"] <= 1.0
+
+
+def test_flickr_eval_flow_base_and_checkpoint(tmp_path):
+    """Script-level flow: JSON dataset -> decode -> GPU preprocessing -> embeddings -> metrics, for the base model and
+    for a Lightning-layout checkpoint; checked against the metrics computed from a plain similarity matrix."""
+    import argparse, json
+    import numpy as np
+    from PIL import Image
+    from dclip_amd import config as dcfg, synth, flickr30k_eval as F, data
+    from dclip_amd.CLIP_image_distillation import CLIPImageDistillation
+    from dclip_amd.clip_model import from_hf_state_dict
+    from dclip_amd.lightning_lite import save_checkpoint
+    dev = torch.device("cuda:0")
+    cfg = dcfg.tiny(image_size=64, patch_size=16)
+    clip = from_hf_state_dict(cfg, synth.synth_clip_state_dict(cfg, seed=3, gain=3.0), device=dev)
+    recs = []
+    for i in range(7):
+        p = tmp_path / f"im{i}.png"
+        Image.fromarray(synth.synth_photo(80 + 7 * i, 100 + 3 * i, seed=i)).save(p)
+        recs.append({"image_id": f"id{i}", "image_path": str(p), "captions": [f"w{i} a{j} photo" for j in range(1 + i % 3)]})
+    recs.append({"image_id": "nocap", "image_path": str(tmp_path / "im0.png"), "captions": []})
+    recs.append({"image_id": "broken", "image_path": str(tmp_path / "missing.png"), "captions": ["x y"]})
+    (tmp_path / "test.json").write_text(json.dumps(recs))
+    T = cfg.text.max_position_embeddings
+
+    def toy_tokenizer(caps):
+        ids = torch.full((len(caps), T), cfg.text.eos_token_id, dtype=torch.int64)
+        ids[:, 0] = cfg.text.bos_token_id
+        for b, c in enumerate(caps):
+            for j, w in enumerate(c.split()[:T - 2]):
+                ids[b, 1 + j] = 1 + (sum(ord(ch) * (k + 1) for k, ch in enumerate(w)) % (cfg.text.bos_token_id - 2))
+        return ids
+
+    m = F.evaluate_model("base", dev, max_images=100, dataset_json=str(tmp_path / "test.json"), clip_model=clip,
+                         tokenizer=toy_tokenizer, batch_size=3)
+    # independent check: host preprocessing, one by one, dense similarity matrix + argsort
+    pre = data.ClipImagePreprocess(64)
+    kept = recs[:7]
+    with torch.no_grad():
+        img = torch.cat([clip.get_image_features(pixel_values=pre(images=Image.open(r["image_path"]))["pixel_values"].to(dev))
+                         for r in kept])
+        caps = [c for r in kept for c in r["captions"]]
+        cap = clip.get_text_features(input_ids=toy_tokenizer(caps).to(dev))
+    owner = [i for i, r in enumerate(kept) for _ in r["captions"]]
+    sim = torch.nn.functional.normalize(cap.double(), dim=1) @ torch.nn.functional.normalize(img.double(), dim=1).t()
+    t2i_rank = [(sim[c] > sim[c, owner[c]]).sum().item() for c in range(len(caps))]
+    assert abs(m["t2i"]["R@1"] - np.mean([r < 1 for r in t2i_rank])) < 1e-12
+    assert abs(m["t2i"]["MAP"] - np.mean([1.0 / (r + 1) for r in t2i_rank])) < 1e-9
+    # checkpoint flow
+    hp = argparse.Namespace(learning_rate=1e-4, warmup_steps=0, total_steps=10, train_batch_size=4, eval_batch_size=4)
+    mod = CLIPImageDistillation(hp, clip, None).to(dev)
+    with torch.no_grad():
+        mod.student.visual_projection.weight.mul_(-1.0)          # make the checkpointed model differ from the base
+    ck = save_checkpoint(str(tmp_path / "ck" / "epoch-epoch=00-train_loss=1.00.ckpt"), mod)
+    base2 = from_hf_state_dict(cfg, synth.synth_clip_state_dict(cfg, seed=3, gain=3.0), device=dev)
+    m2 = F.evaluate_model("custom", dev, max_images=100, dataset_json=str(tmp_path / "test.json"), clip_model=base2,
+                          checkpoint=ck, tokenizer=toy_tokenizer, batch_size=4)
+    assert set(m2) == {"t2i", "i2t"} and set(m2["t2i"]) == {"R@1", "R@5", "R@10", "MAP"}
+    sim2 = -sim                                                   # negated image embeddings flip every similarity
+    t2i_rank2 = [(sim2[c] > sim2[c, owner[c]]).sum().item() for c in range(len(caps))]
+    assert abs(m2["t2i"]["MAP"] - np.mean([1.0 / (r + 1) for r in t2i_rank2])) < 1e-9
