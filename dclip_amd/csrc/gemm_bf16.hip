@@ -8,6 +8,7 @@
 // k = 16s + 8*half + {0..7}, exactly one MFMA operand per ds_read_b128.  At 16x the fp32 MFMA rate the kernel is
 // bounded by L2 -> LDS traffic (64 KB per 512 MFMA cycles per workgroup), not by the matrix pipes.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -214,6 +215,187 @@ __global__ void __launch_bounds__(256, 2) gemm_bf16_kernel(GemmBf16Params p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Large-problem variant (template; instantiated as 256x256x64, 8 waves = 2 x 4, wave tile 128x64 = 4x2 MFMA tiles,
+// one workgroup per CU).  At the bf16 MFMA rate the 128x128 kernel above is bound by its LDS traffic (registers -> ds_write_b128
+// moves 79 B/clk/CU: 32 KB per 512 MFMA cycles).  Here
+//   * global -> LDS goes by `buffer_load_dwordx4 ... lds` (LDS-DMA, gfx950): no staging registers, no ds_write; the
+//     XOR swizzle is applied on the GLOBAL side — lane i of a piece owns LDS granule i, and fetches the 16 bytes
+//     that belong there; rows past M / N are outside the buffer descriptor and arrive as zeros;
+//   * a wave tile of 128x64 needs 6 ds_read_b128 per 8 MFMAs (the 64x64 wave tile: 4 per 4), 37 % of the LDS read
+//     rate at full MFMA rate;
+//   * the next K-tile's 8 DMA pieces per wave are issued before the current tile's 32 MFMAs; one
+//     `s_waitcnt vmcnt(0)` + barrier per K-tile.
+// Requires K % 64 == 0 (a ragged row tail cannot be zeroed on the DMA path) — every projection of the towers.
+// 16 bytes per lane, global -> LDS without passing through registers: lane i lands at lds_dst + 16 i.
+// (A __device__ function on purpose: with the builtin inside a lambda of the kernel template, hipcc 7.2 silently drops
+// the template's host stub.)
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, __bf16* lds_dst, int voff, int soff) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_dst, 16, voff, soff, 0, 0);
+}
+
+template <int BM, int BN, int WM, int WN>
+__global__ void __launch_bounds__(WM * WN * 64) gemm_bf16_dma_kernel(GemmBf16Params p) {
+  constexpr int NW = WM * WN, NTHR = NW * 64;
+  constexpr int TM = BM / WM, TN = BN / WN, MT = TM / 32, NT = TN / 32;
+  constexpr int ROW = BKH;
+  constexpr int STAGE = (BM + BN) * ROW;  // bf16 elements per stage: A tile then B tile
+  constexpr int PA = BM / 8 / NW, PB = BN / 8 / NW;   // DMA pieces (8 rows x 128 B) per wave and K-tile
+  static_assert(PA * NW * 8 == BM && PB * NW * 8 == BN && MT % 2 == 0 && PA + PB == 8, "tile / wave shape");
+  // static LDS (128 KiB for the 256x256 tile): a static declaration may use the whole 160 KiB of a CU
+  __shared__ __attribute__((aligned(16))) unsigned char lds_raw[2 * STAGE * 2];
+  __bf16* lds = reinterpret_cast<__bf16*>(lds_raw);  // [2][A BMx64 | B BNx64]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int l31 = lane & 31, half = lane >> 5;
+
+  constexpr int GROUP_M = 8;
+  const int nwg = p.tiles_m * p.tiles_n;
+  const int swz = xcd_remap16(blockIdx.x, nwg);
+  const int per_group = GROUP_M * p.tiles_n;
+  const int first_m = (swz / per_group) * GROUP_M;
+  const int gsize = min(GROUP_M, p.tiles_m - first_m);
+  const int tile_m = first_m + (swz % per_group) % gsize, tile_n = (swz % per_group) / gsize;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int nk = p.K / BKH;
+
+  const __bf16* a_org = p.A + (size_t)m0 * p.lda;
+  const __bf16* w_org = p.W + (size_t)n0 * p.ldw;
+  const int a_rows = min(BM, p.M - m0), w_rows = min(BN, p.N - n0);
+  const size_t a_bytes = ((size_t)(a_rows - 1) * p.lda + p.K) * 2, w_bytes = ((size_t)(w_rows - 1) * p.ldw + p.K) * 2;
+  const __amdgpu_buffer_rsrc_t a_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a_org), 0, (int)min(a_bytes, (size_t)0x7fffffff), 0x00020000);
+  const __amdgpu_buffer_rsrc_t w_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(w_org), 0, (int)min(w_bytes, (size_t)0x7fffffff), 0x00020000);
+  // piece pc = 8 rows x 8 granules; wave w owns pieces w, w+NW, ... of A and of B.
+  // lane -> (row, stored slot); it fetches logical granule slot ^ ((row>>1)&7) of that row.
+  int a_voff[PA], w_voff[PB];
+#pragma unroll
+  for (int q = 0; q < PA; ++q) {
+    const int row = (wave + NW * q) * 8 + (lane >> 3), g = (lane & 7) ^ ((row >> 1) & 7);
+    a_voff[q] = row < a_rows ? (row * p.lda + g * 8) * 2 : 0x7fffffff;   // out of range -> zeros in LDS
+  }
+#pragma unroll
+  for (int q = 0; q < PB; ++q) {
+    const int row = (wave + NW * q) * 8 + (lane >> 3), g = (lane & 7) ^ ((row >> 1) & 7);
+    w_voff[q] = row < w_rows ? (row * p.ldw + g * 8) * 2 : 0x7fffffff;
+  }
+  // one of this wave's 8 DMA pieces of a stage: x < PA A pieces, then B pieces
+  auto issue_piece = [&](int buf, int kt, int x) {
+    __bf16* sa = lds + buf * STAGE;
+    __bf16* sb = sa + BM * ROW;
+    if (x < PA) dma16(a_rsrc, sa + (wave + NW * x) * 8 * ROW, a_voff[x < PA ? x : 0], kt * (BKH * 2));
+    else dma16(w_rsrc, sb + (wave + NW * (x - PA)) * 8 * ROW, w_voff[x >= PA ? x - PA : 0], kt * (BKH * 2));
+  };
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  auto read_frags = [&](const __bf16* a, const __bf16* b, int s, bf16x8 (&fa)[MT], bf16x8 (&fb)[NT]) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int row = wm * TM + i * 32 + l31;
+      fa[i] = *reinterpret_cast<const bf16x8*>(a + row * ROW + (((2 * s + half) ^ ((row >> 1) & 7)) << 3));
+    }
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int row = wn * TN + j * 32 + l31;
+      fb[j] = *reinterpret_cast<const bf16x8*>(b + row * ROW + (((2 * s + half) ^ ((row >> 1) & 7)) << 3));
+    }
+  };
+
+#pragma unroll
+  for (int x = 0; x < 8; ++x) issue_piece(0, 0, x);
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    const bool more = kt + 1 < nk;
+    const __bf16* a = lds + buf * STAGE;
+    const __bf16* b = a + BM * ROW;
+    bf16x8 fa[2][MT], fb[2][NT];
+    read_frags(a, b, 0, fa[0], fb[0]);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      if (s + 1 < 4) read_frags(a, b, s + 1, fa[(s + 1) & 1], fb[(s + 1) & 1]);
+      // The waves sharing a SIMD run this code in step (one barrier per K-tile): DMA issues are spread two per k-step
+      // BETWEEN halves of the MFMA block, so that while one wave is held in a DMA issue its partner still has matrix
+      // work to feed the pipe with (all eight at the top of the tile would idle it for both).
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s & 1][i], fb[s & 1][j], acc[i][j], 0, 0, 0);
+        if (i == MT / 2 - 1 || i == MT - 1) {
+          __builtin_amdgcn_sched_barrier(0);
+          if (more) issue_piece(buf ^ 1, kt + 1, 2 * s + (i == MT - 1 ? 1 : 0));
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // the next stage has landed (this wave's pieces) ...
+    __syncthreads();                     // ... and everybody's; everyone is done reading `buf`
+  }
+
+  // ---- epilogue: PASSES slabs of rows through the (dead) staging LDS, 16-byte rows out
+  constexpr int LDS_BYTES = 2 * STAGE * 2;
+  constexpr int PASSES = BM * BN * 4 / LDS_BYTES;      // 256x256: 2 (one per wave row), 128x128: 1
+  constexpr int PROWS = BM / PASSES;
+  static_assert(PASSES == 1 || (PASSES == WM && PROWS == TM), "a pass must cover whole wave rows");
+  float* ct = reinterpret_cast<float*>(lds_raw);  // [PROWS][BN]
+#pragma unroll
+  for (int hm = 0; hm < PASSES; ++hm) {
+    if (PASSES == 1 || wm == hm) {
+      const int rbase = PASSES == 1 ? wm * TM : 0;
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            ct[(rbase + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * BN + wn * TN + j * 32 + l31] = acc[i][j][r];
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int q = 0; q < PROWS * BN / 4 / NTHR; ++q) {
+      const int id = tid + q * NTHR;
+      const int lr = id / (BN / 4), lc = (id % (BN / 4)) * 4;
+      const int row = m0 + hm * PROWS + lr, col = n0 + lc;
+      if (row >= p.M || col >= p.N) continue;
+      f32x4 v = *reinterpret_cast<const f32x4*>(ct + lr * BN + lc);
+      if (p.epilogue & DCLIP_EPI_BIAS) v += *reinterpret_cast<const f32x4*>(p.bias + col);
+      if (p.epilogue & DCLIP_EPI_GELU) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = quick_gelu_f(v[e]);
+      }
+      const size_t off = (size_t)row * p.ldc + col;
+      if (p.epilogue & DCLIP_EPI_RESIDUAL) v += *reinterpret_cast<const f32x4*>(p.residual + off);
+      if (p.out_bf16) {
+        u16x4 o = {f32_to_bf16_bits(v[0]), f32_to_bf16_bits(v[1]), f32_to_bf16_bits(v[2]), f32_to_bf16_bits(v[3])};
+        *reinterpret_cast<u16x4*>(reinterpret_cast<unsigned short*>(p.C) + off) = o;
+      } else {
+        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + off) = v;
+      }
+    }
+    if (hm + 1 < PASSES) __syncthreads();
+  }
+}
+
+template <int BM, int BN, int WM, int WN>
+int launch_dma(GemmBf16Params p, hipStream_t st) {
+  p.tiles_m = cdiv(p.M, BM);
+  p.tiles_n = cdiv(p.N, BN);
+  hipLaunchKernelGGL((gemm_bf16_dma_kernel<BM, BN, WM, WN>), dim3(p.tiles_m * p.tiles_n), dim3(WM * WN * 64), 0, st, p);
+  return DCLIP_OK;
+}
+
 // y[i] = bf16(x[i]); rows of `cols` floats written with leading dimension ldy (>= cols, zero padded)
 __global__ void __launch_bounds__(256) cast_bf16_kernel(const float* __restrict__ x, unsigned short* __restrict__ y, int rows,
                                                         int cols, int ldx, int ldy) {
@@ -291,12 +473,23 @@ DCLIP_API int dclip_gemm_bf16(const void* A, const void* W, void* C, const float
   DCLIP_REQUIRE(!(epilogue & ~(DCLIP_EPI_BIAS | DCLIP_EPI_GELU | DCLIP_EPI_RESIDUAL)), "gemm_bf16: unsupported epilogue bits");
   DCLIP_REQUIRE(!(epilogue & DCLIP_EPI_BIAS) || bias, "gemm_bf16: BIAS without bias");
   DCLIP_REQUIRE(!(epilogue & DCLIP_EPI_RESIDUAL) || (residual && !out_bf16), "gemm_bf16: RESIDUAL needs an fp32 output");
+  hipStream_t st = (hipStream_t)stream;
+  // LDS-DMA kernel (K % 64 == 0, at least 128 workgroups): measured faster than the register-staged 128x128
+  // kernel AND than a 128x128 LDS-DMA variant (two workgroups per CU) on every tower shape, short K included
+  // (tools/bf16_gemm_bench.py).  With fp32 outputs and K = 768 it is bound by writing C (944 MB for the qkv
+  // projection of 2048 crops): one workgroup per CU cannot overlap that with the next tile's MFMAs.
+  static const int big_min = getenv("DCLIP_BF16_BIG_MIN") ? atoi(getenv("DCLIP_BF16_BIG_MIN")) : 128;   // tuning aid
+  if (K % BKH == 0 && (long)cdiv(M, 256) * cdiv(N, 256) >= big_min) {
+    GemmBf16Params pb{(const __bf16*)A, (const __bf16*)W, C, bias, residual, M, N, K, lda, ldw, ldc, epilogue, out_bf16, 0, 0};
+    launch_dma<256, 256, 2, 4>(pb, st);
+    DCLIP_CHECK_LAUNCH("gemm_bf16.dma");
+    return DCLIP_OK;
+  }
   const bool small = (long)cdiv(M, 128) * cdiv(N, 128) < 256;  // fewer tiles than CUs: use the finer tile
   const int bm = small ? 64 : 128, bn = bm;
   GemmBf16Params p{(const __bf16*)A, (const __bf16*)W, C, bias, residual, M, N, K, lda, ldw, ldc, epilogue, out_bf16,
                    cdiv(M, bm), cdiv(N, bn)};
   const size_t lds = (size_t)2 * (bm + bn) * BKH * 2;
-  hipStream_t st = (hipStream_t)stream;
   if (small) hipLaunchKernelGGL((gemm_bf16_kernel<64, 64>), dim3(p.tiles_m * p.tiles_n), dim3(256), lds, st, p);
   else hipLaunchKernelGGL((gemm_bf16_kernel<128, 128>), dim3(p.tiles_m * p.tiles_n), dim3(256), lds, st, p);
   DCLIP_CHECK_LAUNCH("gemm_bf16");

@@ -107,3 +107,33 @@ def test_meta_teacher_bf16_towers_close_to_fp32():
     cos = torch.nn.functional.cosine_similarity(outs["fp32"], outs["bf16"], dim=1)
     print("meta-teacher bf16 towers: min cosine", float(cos.min()))
     assert float(cos.min()) > 0.999
+
+
+def test_gemm_bf16_big_tile_kernel_matches(monkeypatch):
+    """The 256x256 LDS-DMA kernel, forced onto small shapes (DCLIP_BF16_BIG_MIN=1 is read once per process: this test
+    runs the comparison in a child process), against the fp64 product of the rounded inputs."""
+    import subprocess, sys, os, textwrap
+    code = textwrap.dedent("""
+        import torch, sys
+        sys.path.insert(0, %r)
+        from dclip_amd import ops
+        dev = torch.device("cuda:0")
+        for M, N, K in [(256, 256, 64), (1000, 520, 128), (257, 260, 192), (2048, 3072, 768), (4100, 768, 3072), (77, 768, 768)]:
+            g = torch.Generator().manual_seed(M + N + K)
+            a, w = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) * 0.1
+            bias, res = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+            a16, w16 = ops.cast_bf16(a.to(dev)), ops.cast_bf16(w.to(dev))
+            want = a.to(torch.bfloat16).double() @ w.to(torch.bfloat16).double().t() + bias.double()
+            got = ops.gemm_bf16(a16, w16, k=K, bias=bias.to(dev))
+            err = float((got.double().cpu() - want).abs().max() / want.abs().max())
+            assert err < 2e-6 * max(1.0, K ** 0.5), (M, N, K, err)
+            got2 = ops.gemm_bf16(a16, w16, k=K, bias=bias.to(dev), residual=res.to(dev))
+            assert float((got2.double().cpu() - (want + res.double())).abs().max() / want.abs().max()) < 1e-5
+            g16 = ops.gemm_bf16(a16, w16, k=K, bias=bias.to(dev), gelu=True, out_bf16=True)
+            ref = (want * torch.sigmoid(1.702 * want)).to(torch.bfloat16)
+            assert float((g16.cpu().double() - ref.double()).abs().max() / ref.double().abs().max()) < 1e-2
+        print("OK")
+    """) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DCLIP_BF16_BIG_MIN="1")
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0 and "OK" in p.stdout, p.stdout[-2000:] + p.stderr[-2000:]

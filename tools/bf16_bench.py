@@ -21,7 +21,7 @@ def timeit(f, n=20, w=5):
     return e0.elapsed_time(e1) / n
 
 
-for M, N, K in [(12800, 2304, 768), (12800, 768, 768), (12800, 3072, 768), (12800, 768, 3072), (12544, 768, 3072),
+for M, N, K in [(102400, 2304, 768), (102400, 768, 768), (102400, 3072, 768), (102400, 768, 3072), (12800, 2304, 768), (12800, 768, 768), (12800, 3072, 768), (12800, 768, 3072), (12544, 768, 3072),
                 (65792, 3072, 1024), (65792, 1024, 4096)]:
     a = torch.randn(M, K, device=dev).to(torch.bfloat16)
     w = torch.randn(N, K, device=dev).to(torch.bfloat16)
