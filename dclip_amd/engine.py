@@ -288,9 +288,9 @@ def _w16(cache: dict, key: str, w: torch.Tensor) -> torch.Tensor:
 
 def _layer_fwd_bf16(x, p: LayerParams, c: dict, pre: str, B: int, S: int, H: int, causal: bool, eps: float):
     ln1 = ops.layernorm_fwd_bf16(x, p.ln1_w, p.ln1_b, eps)
-    qkv = ops.gemm_bf16(ln1, _w16(c, pre + "qkv", p.qkv_w), bias=p.qkv_b)
-    attn, _ = ops.attention_fwd(qkv, B, S, H, causal)
-    x1 = ops.gemm_bf16(ops.cast_bf16(attn), _w16(c, pre + "out", p.out_w), bias=p.out_b, residual=x)
+    qkv = ops.gemm_bf16(ln1, _w16(c, pre + "qkv", p.qkv_w), bias=p.qkv_b, out_bf16=True)
+    attn = ops.attention_fwd_bf16(qkv, B, S, H, causal)       # bf16 q/k/v in, bf16 context out: no cast pass
+    x1 = ops.gemm_bf16(attn, _w16(c, pre + "out", p.out_w), bias=p.out_b, residual=x)
     ln2 = ops.layernorm_fwd_bf16(x1, p.ln2_w, p.ln2_b, eps)
     g = ops.gemm_bf16(ln2, _w16(c, pre + "fc1", p.fc1_w), bias=p.fc1_b, gelu=True, out_bf16=True)
     return ops.gemm_bf16(g, _w16(c, pre + "fc2", p.fc2_w), bias=p.fc2_b, residual=x1)

@@ -553,6 +553,18 @@ def layernorm_fwd_bf16(x, gamma, beta, eps: float) -> torch.Tensor:
     return y
 
 
+def attention_fwd_bf16(qkv: torch.Tensor, B: int, S: int, H: int, causal: bool) -> torch.Tensor:
+    """qkv [B*S, 3*H*64] bf16 -> context [B*S, H*64] bf16 (frozen towers, forward only)."""
+    lib = _lib.load()
+    _bf16(qkv, "qkv")
+    if tuple(qkv.shape) != (B * S, 3 * H * 64):
+        raise ValueError(f"attention_fwd_bf16: qkv shape {tuple(qkv.shape)} != {(B * S, 3 * H * 64)}")
+    out = torch.empty((B * S, H * 64), dtype=torch.bfloat16, device=qkv.device)
+    _lib.check(lib.dclip_attention_fwd_bf16(qkv.data_ptr(), out.data_ptr(), B, S, H, int(causal), _stream()),
+               "attention_fwd_bf16")
+    return out
+
+
 def gemm_bf16(a: torch.Tensor, w: torch.Tensor, *, n: Optional[int] = None, k: Optional[int] = None,
               bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None, gelu: bool = False,
               out_bf16: bool = False) -> torch.Tensor:

@@ -274,6 +274,9 @@ int dclip_clip_preprocess_u8(const uint8_t* images, const int32_t* dims, float* 
 int dclip_gemm_bf16(const void* A, const void* W, void* C, const float* bias, const float* residual, int M, int N,
                     int K, int lda, int ldw, int ldc, int epilogue, int out_bf16, void* stream);
 int dclip_cast_f32_bf16(const float* x, void* y, int rows, int cols, int ldx, int ldy, void* stream);
+/* Softmax attention of the frozen towers on bf16 q/k/v (the fused projection [B*S, 3*H*64] as written by
+ * dclip_gemm_bf16 with out_bf16): fp32 scores / softmax, bf16 P and context [B*S, H*64].  Forward only. */
+int dclip_attention_fwd_bf16(const void* qkv, void* out, int B, int S, int H, int causal, void* stream);
 int dclip_layernorm_fwd_bf16(const float* x, const float* gamma, const float* beta, void* y, int rows, int D,
                              float eps, void* stream);
 

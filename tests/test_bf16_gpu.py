@@ -137,3 +137,22 @@ def test_gemm_bf16_big_tile_kernel_matches(monkeypatch):
     env = dict(os.environ, DCLIP_BF16_BIG_MIN="1")
     p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
     assert p.returncode == 0 and "OK" in p.stdout, p.stdout[-2000:] + p.stderr[-2000:]
+
+
+@pytest.mark.parametrize("B,S,H,causal", [(2, 50, 2, False), (2, 77, 2, True), (1, 257, 2, False), (1, 197, 1, False),
+                                          (3, 64, 1, True), (2, 1, 1, False), (1, 130, 2, True), (2, 33, 3, False)])
+def test_attention_fwd_bf16(B, S, H, causal):
+    """bf16 q/k/v, fp32 softmax, bf16 P and output: against an fp64 attention of the same rounded inputs."""
+    from dclip_amd import ops
+    dev = torch.device("cuda:0")
+    D = H * 64
+    qkv = (rnd((B * S, 3 * D), 7 + S, 1.2)).to(torch.bfloat16)
+    q, k, v = (qkv.double().view(B, S, 3, H, 64)[:, :, i].transpose(1, 2) for i in range(3))
+    s = (q @ k.transpose(-1, -2)) * 0.125
+    if causal:
+        s = s + torch.full((S, S), float("-inf"), dtype=torch.float64).triu(1)
+    want = (torch.softmax(s, dim=-1) @ v).transpose(1, 2).reshape(B * S, D)
+    got = ops.attention_fwd_bf16(qkv.to(dev), B, S, H, causal)
+    assert got.dtype == torch.bfloat16 and tuple(got.shape) == (B * S, D)
+    err = float((got.double().cpu() - want).abs().max() / want.abs().max())
+    assert err < 1.5e-2, err          # bf16 rounding of P (2^-9 relative) and of the output

@@ -50,3 +50,14 @@ for name, B, S, H, causal in [("vision B/32", 256, 50, 12, False), ("text", 256,
         err = float((g1 - g2).abs().max() / g2.abs().max())
         mb = (8 * B * S * H * 64 * 4) / 1e6
         print(f"{name}: rows {a:.1f} us ({mb / a / 1e3:.2f} TB/s) | previous {b:.1f} us | max rel diff {err:.2e}", flush=True)
+
+print("--- bf16 forward (frozen towers)")
+for name, B, S, H, causal in [("regions B/32", 2048, 50, 12, False), ("L/14", 64, 257, 16, False), ("B/16", 128, 197, 12, False),
+                              ("text", 256, 77, 8, True)]:
+    os.environ.pop("DCLIP_ATTN_TILED", None)
+    qkv = torch.randn(B * S, 3 * H * 64, device=dev)
+    q16 = qkv.to(torch.bfloat16)
+    a = t(lambda: ops.attention_fwd(qkv, B, S, H, causal))
+    b = t(lambda: ops.attention_fwd_bf16(q16, B, S, H, causal))
+    fl = 4.0 * S * S * 64 * B * H
+    print(f"{name}: fp32 {a:.1f} us ({fl / a / 1e6:.0f} TF/s) | bf16 {b:.1f} us ({fl / b / 1e6:.0f} TF/s)", flush=True)
