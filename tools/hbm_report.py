@@ -9,7 +9,7 @@ B, S, D, H, I = 256, 50, 768, 12, 3072            # ViT-B/32 vision tower at bs 
 T, Dt = 77, 512                                   # text tower
 rows_v, rows_t = B * S, B * T
 F = 4
-trainable = 87_849_216 + 393_216 + 1              # vision tower + visual_projection + logit_scale (north_star regime)
+trainable = 87_456_000 + 393_216 + 1              # vision tower + visual_projection + logit_scale (north_star regime)
 KERNELS = {
     "ln_fwd_kernel<3>": ("LayerNorm fwd, vision rows (x read, y written, 8 B/elem)", 2 * rows_v * D * F),
     "ln_fwd_kernel<2>": ("LayerNorm fwd, text rows", 2 * rows_t * Dt * F),
