@@ -54,6 +54,7 @@ SIGNATURES = {
     "dclip_aggregation_fwd": (I, [P, P, P, I, I, I, F, F, I, P]),
     "dclip_aggregation_bwd": (I, [P, P, P, P, I, I, I, F, F, P]),
     "dclip_pack_tokens": (I, [P, P, P, P, I, I, I, I, P]),
+    "dclip_sanitize_groups": (I, [P, P, I, I, I, I, P]),
     "dclip_mask_rows": (I, [P, P, I, I, I, P]),
     "dclip_rank_count_workspace": (Z, [I, I]),
     "dclip_rowdot_gather": (I, [P, P, P, P, I, I, I, P]),

@@ -199,6 +199,30 @@ __global__ void __launch_bounds__(256) mask_rows_kernel(float* __restrict__ x, c
   }
 }
 
+// NaN / Inf guards of the reference's glue (training/patch_text_aggregation.py:497-499 per region embedding, :542 per
+// caption, :649 for the whole batch): a GROUP of `rows` consecutive rows that holds any non-finite value is replaced
+// by zeros.  mode 0: detect (flags[g] = 1 / 0) and zero; mode 1: zero the groups whose flag is already set (backward).
+__global__ void __launch_bounds__(256) sanitize_groups_kernel(float* __restrict__ x, int32_t* __restrict__ flags, size_t n4,
+                                                              int mode) {
+  f32x4* g = reinterpret_cast<f32x4*>(x) + (size_t)blockIdx.x * n4;
+  int bad;
+  if (mode == 0) {
+    int mine = 0;
+    for (size_t i = threadIdx.x; i < n4; i += 256) {
+      const f32x4 v = g[i];
+      // finite <=> |v| <= FLT_MAX; NaN compares false
+#pragma unroll
+      for (int e = 0; e < 4; ++e) mine |= (int)!(fabsf(v[e]) <= 3.402823466e38f);
+    }
+    bad = __syncthreads_or(mine);
+    if (threadIdx.x == 0) flags[blockIdx.x] = bad ? 1 : 0;
+  } else {
+    bad = flags[blockIdx.x];
+  }
+  if (bad)
+    for (size_t i = threadIdx.x; i < n4; i += 256) g[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+}
+
 inline int grid_for(size_t work) {
   size_t b = (work + 255) / 256;
   return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
@@ -245,5 +269,14 @@ DCLIP_API int dclip_mask_rows(float* x, const int32_t* count, int B, int R, int 
   const size_t total4 = (size_t)B * R * E / 4;
   hipLaunchKernelGGL(mask_rows_kernel, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)stream, x, count, R, E / 4, total4);
   DCLIP_CHECK_LAUNCH("mask_rows");
+  return DCLIP_OK;
+}
+
+DCLIP_API int dclip_sanitize_groups(float* x, int32_t* flags, int groups, int rows, int E, int mode, void* stream) {
+  DCLIP_REQUIRE(x && flags && groups > 0 && rows > 0 && E > 0 && E % 4 == 0 && (mode == 0 || mode == 1),
+                "sanitize_groups: bad arguments");
+  hipLaunchKernelGGL(sanitize_groups_kernel, dim3(groups), dim3(256), 0, (hipStream_t)stream, x, flags,
+                     (size_t)rows * E / 4, mode);
+  DCLIP_CHECK_LAUNCH("sanitize_groups");
   return DCLIP_OK;
 }

@@ -523,6 +523,24 @@ def mask_rows(x, count):
     return x
 
 
+def sanitize_groups(x: torch.Tensor, rows: int, flags: Optional[torch.Tensor] = None):
+    """x viewed as [groups, rows, E]: groups holding a NaN / Inf become zeros IN PLACE.  flags=None: detect (returns
+    the int32 flags); flags given: zero the flagged groups (backward of the guard)."""
+    lib = _lib.load()
+    _f32(x, "x")
+    E = x.shape[-1]
+    total_rows = x.numel() // E
+    if total_rows % rows:
+        raise ValueError("sanitize_groups: rows must divide the row count")
+    groups = total_rows // rows
+    mode = 0 if flags is None else 1
+    if flags is None:
+        flags = torch.empty((groups,), dtype=torch.int32, device=x.device)
+    _lib.check(lib.dclip_sanitize_groups(x.data_ptr(), flags.data_ptr(), groups, rows, E, mode, _stream()),
+               "sanitize_groups")
+    return x, flags
+
+
 # ------------------------------------------------------------------------------------------- bf16 frozen-tower path
 
 def _bf16(t: torch.Tensor, name: str) -> torch.Tensor:

@@ -104,8 +104,17 @@ class CrossModalFn(torch.autograd.Function):
         if need_x:
             d_text = ops.axpby(dxkv_i, dxq_t, 1.0, 1.0).view(B, T, E)
             d_patch = ops.axpby(dxkv_t, dxq_i, 1.0, 1.0).view(B, R, E)
+        grads = [d_text, d_patch, None, gt[0], gt[1], gt[2], gt[3], gi[0], gi[1], gi[2], gi[3], gt[4], gt[5], gi[4], gi[5]]
+        flag = getattr(ctx, "replaced_flag", None)
+        if flag is not None:
+            # the batch was replaced by zeros downstream (NaN / Inf guard, :649-651): in the reference that result is
+            # a fresh tensor with no graph, so nothing reaches this block; the saved activations hold the NaNs, so the
+            # gradients are zeroed rather than trusted
+            for g in grads:
+                if g is not None:
+                    ops.sanitize_groups(g.view(1, -1) if g.dim() == 1 else g, g.numel() // g.shape[-1], flag)
         # parameter order: t.{in_w,in_b,out_w,out_b}, i.{...}, norm_text.{w,b}, norm_image.{w,b}
-        return (d_text, d_patch, None, gt[0], gt[1], gt[2], gt[3], gi[0], gi[1], gi[2], gi[3], gt[4], gt[5], gi[4], gi[5])
+        return tuple(grads)
 
 
 class CrossModalAttention(nn.Module):
@@ -138,16 +147,24 @@ class GlobalPoolFn(torch.autograd.Function):
         at, ai = at.detach().contiguous(), ai.detach().contiguous()
         out, wt = ops.aggregation_fwd(at, temperature, out_scale=0.5)
         _, wi = ops.aggregation_fwd(ai, temperature, out=out, out_scale=0.5, accumulate=True)
-        ctx.save_for_backward(at, ai, wt, wi)
+        # :649-651 — any NaN / Inf anywhere in the [B,E] result replaces the WHOLE batch by zeros
+        _, flag = ops.sanitize_groups(out, out.shape[0])
+        ctx.replaced_flag = flag
+        ctx.save_for_backward(at, ai, wt, wi, flag)
         ctx.temperature = temperature
         return out
 
     @staticmethod
     def backward(ctx, d_out):
-        at, ai, wt, wi = ctx.saved_tensors
+        at, ai, wt, wi, flag = ctx.saved_tensors
         d_out = d_out.contiguous()
-        return (ops.aggregation_bwd(at, wt, d_out, ctx.temperature, 0.5),
-                ops.aggregation_bwd(ai, wi, d_out, ctx.temperature, 0.5), None)
+        d_at = ops.aggregation_bwd(at, wt, d_out, ctx.temperature, 0.5)
+        d_ai = ops.aggregation_bwd(ai, wi, d_out, ctx.temperature, 0.5)
+        # a replaced batch is a fresh zeros tensor in the reference: NO gradient reaches the block (the saved
+        # activations hold the NaNs, so the gradients themselves are zeroed, not just d_out)
+        ops.sanitize_groups(d_at, d_at.shape[0] * d_at.shape[1], flag)
+        ops.sanitize_groups(d_ai, d_ai.shape[0] * d_ai.shape[1], flag)
+        return d_at, d_ai, None
 
 
 class AggregationFn(torch.autograd.Function):
@@ -369,9 +386,18 @@ class PatchTextAggregation(nn.Module):
         return self.global_embedding_from_tokens(text, emb)
 
     def global_embedding_from_tokens(self, text: torch.Tensor, patches: torch.Tensor) -> torch.Tensor:
-        """[B,Tmax,E], [B,Rmax,E] (zero-padded) -> [B,E]: :634-647."""
+        """[B,Tmax,E], [B,Rmax,E] (zero-padded) -> [B,E]: :634-651, with the reference's NaN / Inf guards: a region
+        embedding that is not finite becomes a zero row (:497-499), a caption with any non-finite token embedding
+        becomes all zeros (:542-544), a non-finite result zeroes the whole batch (:649-651)."""
+        if not (text.requires_grad or patches.requires_grad):       # frozen tower outputs: guard in place on copies
+            text, patches = text.detach().clone().contiguous(), patches.detach().clone().contiguous()
+            ops.sanitize_groups(patches, 1)
+            ops.sanitize_groups(text, text.shape[1])
         at, ai = self.cross_modal_attention(text, patches)
-        return GlobalPoolFn.apply(at, ai, 2.0)
+        out = GlobalPoolFn.apply(at, ai, 2.0)
+        if out.grad_fn is not None and at.grad_fn is not None:
+            at.grad_fn.replaced_flag = out.grad_fn.replaced_flag       # lets the block's backward honour guard (3)
+        return out
 
     # ---- the reference's path-based signature
     def compute_global_embedding_batch(self, image_paths, texts, weighted_boxes_batch=None, images_u8=None, dims=None):

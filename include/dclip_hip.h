@@ -216,6 +216,10 @@ int dclip_aggregation_bwd(const float* x, const float* weights, const float* dou
 int dclip_pack_tokens(const float* tokens, const float* sentence, const int32_t* eos, float* out, int B, int T,
                       int Tmax, int P, void* stream);
 int dclip_mask_rows(float* x, const int32_t* count, int B, int R, int E, void* stream);
+/* NaN / Inf guards of the reference's teacher glue (training/patch_text_aggregation.py:497-499, :542, :649): x is
+ * [groups][rows][E]; a group holding any non-finite value becomes zeros.  mode 0: detect, write flags[groups]
+ * (1 = replaced) and zero in place; mode 1: zero the groups already flagged (the guard's backward). */
+int dclip_sanitize_groups(float* x, int32_t* flags, int groups, int rows, int E, int mode, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Checkpoint consumers: retrieval and zero-shot evaluation on the similarity kernel.

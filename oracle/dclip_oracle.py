@@ -214,8 +214,17 @@ def global_embedding(p: Dict[str, Tensor], text: Tensor, patches: Tensor, heads:
     """Tail of `compute_global_embedding_batch` — training/patch_text_aggregation.py:634-647:
     cross-attention, aggregate each side, 0.5/0.5 mix.  Inputs are already zero-padded
     ([B,Tmax,E], [B,Rmax,E]); padded rows are attended to and pooled."""
+    # NaN / Inf guards: a non-finite region embedding -> zero row (:497-499); a caption with any non-finite token
+    # embedding -> all zeros (:542-544); a non-finite result -> the whole batch zeros (:649-651)
+    row_ok = torch.isfinite(patches).all(dim=-1, keepdim=True)
+    patches = torch.where(row_ok, patches, torch.zeros_like(patches))
+    cap_ok = torch.isfinite(text).flatten(1).all(dim=1).view(-1, 1, 1)
+    text = torch.where(cap_ok, text, torch.zeros_like(text))
     at, ai = cross_modal_attention(p, text, patches, heads, prefix)
-    return 0.5 * aggregation(at) + 0.5 * aggregation(ai)
+    out = 0.5 * aggregation(at) + 0.5 * aggregation(ai)
+    if not bool(torch.isfinite(out).all()):
+        out = torch.zeros_like(out)
+    return out
 
 
 def pad_regions(region_embs: Sequence[Tensor], embed_dim: int) -> Tensor:

@@ -375,6 +375,69 @@ def gen_teacher_glue(pta, tt, it):
     save("teacher_glue.npz", **arrs)
 
 
+def gen_teacher_guards(pta, tt, it):
+    """NaN / Inf guards of the reference's glue, run as written (training/patch_text_aggregation.py:497-499, :542-544,
+    :649-651): one region crop holds a NaN pixel (-> its embedding is non-finite -> zero row), one caption uses a
+    token whose embedding row is NaN (-> that caption's token embeddings become zeros), and a second run with a NaN
+    LayerNorm weight in the cross-modal block (-> the whole batch becomes zeros)."""
+    from PIL import Image
+    cfg = dcfg.tiny()
+    NAN_ID = 77
+    sd = synth.synth_clip_state_dict(cfg, seed=7, gain=4.0)
+    sd["text_model.embeddings.token_embedding.weight"][NAN_ID] = float("nan")
+    m = TensorReturning(hf_model(cfg, sd))
+    E = cfg.projection_dim
+    captions = ["a", "b", "c"]
+    ids = synth.synth_input_ids(3, cfg.text, seed=43, ragged=True, min_len=5)
+    ids[1, 2] = NAN_ID
+    id_by_caption = dict(zip(captions, ids))
+
+    class FakeTok:
+        def __call__(self, text, **kw):
+            row = id_by_caption[text]
+            n = int((row == cfg.text.eos_token_id).int().argmax()) + 1
+            out = types.SimpleNamespace(input_ids=row[:n].unsqueeze(0), attention_mask=torch.ones(1, n, dtype=torch.long))
+            out.to = lambda dev: out
+            return out
+
+    n_regions = [3, 2, 1]
+    regions = synth.synth_regions(3, 3, cfg.vision, seed=5)
+    regions[0, 1, 0, 3, 4] = float("nan")
+    outs = {}
+    for name, poison in (("global", False), ("global_poisoned_block", True)):
+        cmsd = synth.synth_cross_modal_state_dict(E, seed=33)
+        if poison:
+            cmsd["norm_text.weight"][3] = float("nan")
+        text_tok = object.__new__(tt.CLIPTextTokenizer)
+        text_tok.tokenizer, text_tok.model, text_tok.device = FakeTok(), m, "cpu"
+        queue = []
+        patch_tok = object.__new__(it.CLIPPatchTokenizer)
+        patch_tok.clip_model, patch_tok.device = m, torch.device("cpu")
+        patch_tok.patch_transform = lambda pil: queue.pop(0)
+        teacher = object.__new__(pta.PatchTextAggregation)
+        nn.Module.__init__(teacher)
+        teacher.embed_dim, teacher.device = E, torch.device("cpu")
+        teacher.text_tokenizer, teacher.patch_tokenizer = text_tok, patch_tok
+        teacher.cross_modal_attention = pta.CrossModalAttention(E, E // 64)
+        teacher.cross_modal_attention.load_state_dict(cmsd)
+        teacher.knn_cache, teacher.use_knn_projection, teacher.advanced_tokenizer = {}, False, None
+        teacher.full_resolution = False
+        with tempfile.TemporaryDirectory() as d:
+            paths, boxes = [], []
+            for b in range(3):
+                pth = os.path.join(d, f"{b}.png")
+                Image.new("RGB", (96, 80), (10 * b, 20, 30)).save(pth)
+                paths.append(pth)
+                boxes.append([((4 * r, 2 * r, 40 + 4 * r, 30 + 2 * r), 0.9 - 0.1 * r) for r in range(n_regions[b])])
+                queue.extend(regions[b, r] for r in range(n_regions[b]))
+            with torch.no_grad():
+                outs[name] = teacher.compute_global_embedding_batch(paths, captions, boxes)
+    assert bool(torch.isfinite(outs["global"]).all()) and float(outs["global"].abs().sum()) > 0
+    assert float(outs["global_poisoned_block"].abs().sum()) == 0.0
+    save("teacher_guards.npz", input_ids=ids, regions=regions, n_regions=np.array(n_regions), cm_seed=np.array(33),
+         clip_seed=np.array(7), nan_token_id=np.array(NAN_ID), **outs)
+
+
 # ----------------------------------------------------------------------------- F4 full step, config c1
 
 def gen_step_c1(ref_con, ref_cos):
@@ -523,6 +586,8 @@ def main():
         gen_towers_tiny()
     if not which or "teacher_glue" in which:
         gen_teacher_glue(pta, tt, it)
+    if not which or "teacher_guards" in which:
+        gen_teacher_guards(pta, tt, it)
     if not which or "towers_real" in which:
         gen_towers_real()
     if not which or "step_c1" in which:

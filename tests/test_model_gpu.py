@@ -299,6 +299,35 @@ def test_teacher_glue_against_reference(dev, golden):
         assert relerr(toks, g[f"tokens.{b}"]) < 1e-3
 
 
+def test_teacher_nan_guards_against_reference(dev, golden):
+    """training/patch_text_aggregation.py:497-499, :542-544, :649-651 as run by the reference itself: NaN region crop ->
+    zero row, NaN token embedding -> that caption's tokens zero, NaN inside the block -> whole batch zero (and no
+    gradient)."""
+    from dclip_amd.patch_text_aggregation import PatchTextAggregation
+    g = golden("teacher_guards.npz")
+    cfg = dcfg.tiny()
+    sd = synth.synth_clip_state_dict(cfg, seed=int(g["clip_seed"]), gain=4.0)
+    sd["text_model.embeddings.token_embedding.weight"][int(g["nan_token_id"])] = float("nan")
+    clip = make_model(cfg, sd, dev)
+    ids, regions, n_regions = T(g["input_ids"]).to(dev), T(g["regions"]).to(dev), T(g["n_regions"])
+    cm = synth.synth_cross_modal_state_dict(cfg.projection_dim, seed=int(g["cm_seed"]))
+
+    def teacher_with(weights):
+        t = PatchTextAggregation(embed_dim=cfg.projection_dim, num_heads=cfg.projection_dim // 64, clip_model=clip)
+        t.load_state_dict({f"cross_modal_attention.{k}": v for k, v in weights.items()})
+        return t.to(dev)
+
+    glob = teacher_with(cm).compute_global_embedding_tensors(regions, ids, n_regions)
+    assert bool(torch.isfinite(glob).all()) and relerr(glob, g["global"]) < 1e-3
+    cm["norm_text.weight"][3] = float("nan")
+    t2 = teacher_with(cm)
+    out = t2.compute_global_embedding_tensors(regions, ids, n_regions)
+    assert float(out.abs().sum()) == 0.0
+    out.sum().backward()
+    for n, p in t2.cross_modal_attention.named_parameters():
+        assert p.grad is None or float(p.grad.abs().sum()) == 0.0, n       # a replaced batch passes no gradient
+
+
 def test_teacher_path_based_signature(dev, tmp_path):
     """compute_global_embedding_batch(paths, texts, boxes) == the tensor variant on the crops it cuts."""
     from PIL import Image

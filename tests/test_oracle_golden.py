@@ -203,6 +203,29 @@ def test_teacher_glue(golden):
     close(glob, g["global"], rtol=1e-4, atol=1e-5)
 
 
+def test_teacher_nan_guards(golden):
+    """The reference's NaN / Inf guards (run as written when the golden was made): a NaN region crop, a caption
+    through a NaN token embedding, and a NaN weight inside the cross-modal block (whole batch -> zeros)."""
+    g = golden("teacher_guards.npz")
+    cfg = dcfg.tiny()
+    sd = synth.synth_clip_state_dict(cfg, seed=int(g["clip_seed"]), gain=4.0)
+    sd["text_model.embeddings.token_embedding.weight"][int(g["nan_token_id"])] = float("nan")
+    ids, regions, n_regions = T(g["input_ids"]), T(g["regions"]), g["n_regions"]
+    assert bool(torch.isnan(regions).any())
+    with torch.no_grad():
+        toks, n_tok, _ = O.teacher_token_embeddings(sd, ids, cfg.text)
+        assert bool(torch.isnan(toks[1]).any())
+        embs = [O.vision_tower(sd, regions[b, :int(n_regions[b])], cfg.vision) for b in range(ids.shape[0])]
+        assert not bool(torch.isfinite(embs[0][1]).all()) and bool(torch.isfinite(embs[0][0]).all())
+        patches = O.pad_regions(embs, cfg.projection_dim)
+        cm = synth.synth_cross_modal_state_dict(cfg.projection_dim, seed=int(g["cm_seed"]))
+        glob = O.global_embedding(cm, toks, patches, heads=cfg.projection_dim // 64)
+        close(glob, g["global"], rtol=1e-4, atol=1e-5)
+        cm["norm_text.weight"][3] = float("nan")
+        glob2 = O.global_embedding(cm, toks, patches, heads=cfg.projection_dim // 64)
+    assert float(glob2.abs().sum()) == 0.0 and float(np.abs(g["global_poisoned_block"]).sum()) == 0.0
+
+
 # ---------------------------------------------------------------- F4 full step (config c1)
 
 @pytest.mark.timeout(600)
