@@ -53,4 +53,17 @@ for name, layout, m, n, k, epi in SHAPES[args.shapes]:
     e1.record()
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / args.iters
-    print(f"{name:24s} M={m:6d} N={n:5d} K={k:6d}  {us:8.1f} us  {2.0*m*n*k/us/1e6:7.1f} TF/s", flush=True)
+    # the library path PyTorch would take for the same product (rocBLAS / hipBLASLt fp32), bare matmul without epilogue
+    ta = a if layout & 1 else a.t()
+    tb = b.t() if layout & 2 else b
+    for _ in range(3):
+        torch.matmul(ta, tb, out=out)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(args.iters):
+        torch.matmul(ta, tb, out=out)
+    e1.record()
+    torch.cuda.synchronize()
+    us_t = e0.elapsed_time(e1) * 1e3 / args.iters
+    print(f"{name:24s} M={m:6d} N={n:5d} K={k:6d}  {us:8.1f} us  {2.0*m*n*k/us/1e6:7.1f} TF/s | torch.matmul (no epilogue) "
+          f"{us_t:8.1f} us {2.0*m*n*k/us_t/1e6:7.1f} TF/s", flush=True)
