@@ -326,6 +326,125 @@ __global__ void __launch_bounds__(KT * 64) attn_fwd_rows_kernel(AttnArgs a, floa
   }
 }
 
+// ------------------------------------------------------------------------------------------- forward, streamed
+// Long self-attention (ViT-B/16's 197 tokens, ViT-L/14's 257): flash-style, same register discipline as the whole-row
+// kernel but on v_mfma_f32_32x32x2_f32.  One wave per 32 queries, four waves per workgroup, keys streamed through
+// 64-row LDS tiles.  Scores come out transposed (S^T = K Q^T): lane (l31, half) owns query column l31 and holds the
+// keys {(r&3) + 8(r>>2) + 4 half} of a 32-key block in registers r = 0..15 — which is exactly the pair of keys one
+// 32x32x2 MFMA step r of O^T = V^T P^T contracts (k-slot = half).  P never leaves registers; the running max / sum
+// and the accumulator rescale are per-lane scalars; O^T leaves as 16-byte stores.
+template <bool CAUSAL>
+__global__ void __launch_bounds__(256) attn_fwd_stream_kernel(AttnArgs a, float* __restrict__ out, float* __restrict__ lse) {
+  // (a double-buffered LDS-DMA staging of the K / V tiles was measured SLOWER here: 272 vs 255 us at B/16 — the
+  // second stage halves the workgroups per CU's LDS headroom and the DMA issue competes with the MFMA stream)
+  __shared__ __attribute__((aligned(16))) float lds[2 * TS * HD];
+  float* Ks = lds;
+  float* Vs = lds + TS * HD;
+  const int H = a.H, S = a.Sk;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l31 = lane & 31, half = lane >> 5;
+  const int bh = blockIdx.x, b = bh / H, h = bh % H;
+  const int D = H * HD;
+  const int q0 = blockIdx.y * 128 + wave * 32;
+  const int query = q0 + l31;
+  const float* kbase = a.k + (size_t)b * S * a.ldkv + h * HD;
+  const float* vbase = a.v + (size_t)b * S * a.ldkv + h * HD;
+  // Q fragments (B operand): step (g, r) of the 32 k=2 steps contracts head dims 8g + 4 half + r
+  f32x4 qf[8];
+  {
+    const float* qrow = a.q + ((size_t)b * S + min(query, S - 1)) * a.ldq + h * HD + 4 * half;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) qf[g] = *reinterpret_cast<const f32x4*>(qrow + 8 * g);
+  }
+  f32x16 o[2];
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+  float m = -INFINITY, l = 0.f;
+  const bool wave_live = q0 < S;                        // a wave past the end only helps staging
+  int nkt = (S + TS - 1) / TS;
+  if (CAUSAL) nkt = min(nkt, (int)(blockIdx.y * 128 + 127) / TS + 1);
+  for (int kt = 0; kt < nkt; ++kt) {
+    if (kt > 0) __syncthreads();
+    stage_tile(Ks, kbase, kt * TS, S, (size_t)a.ldkv);
+    stage_tile(Vs, vbase, kt * TS, S, (size_t)a.ldkv);
+    __syncthreads();
+    if (!wave_live || (CAUSAL && kt * TS > q0 + 31)) continue;
+    // second 32-key half of the tile: skipped when it holds no key this wave needs (wave-uniform)
+    const bool sub1 = kt * TS + 32 < S && !(CAUSAL && kt * TS + 32 > q0 + 31);
+    f32x16 st[2];
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) st[sub][r] = 0.f;
+      if (sub == 1 && !sub1) continue;
+      const int krow = 32 * sub + l31;
+#pragma unroll
+      for (int g = 0; g < 8; ++g) {
+        // 16 bytes of key row krow: head dims 8g + 4 half .. +3 (tile_off keeps 4-float slots contiguous)
+        const f32x4 kf = *reinterpret_cast<const f32x4*>(Ks + krow * HD + (((2 * g + half) ^ (krow & 15)) << 2));
+#pragma unroll
+        for (int r = 0; r < 4; ++r) st[sub] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[r], qf[g][r], st[sub], 0, 0, 0);
+      }
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = kt * TS + 32 * sub + (r & 3) + 8 * (r >> 2) + 4 * half;
+        float v = st[sub][r] * kScale;
+        if (key >= S || (CAUSAL && key > query)) v = -INFINITY;
+        st[sub][r] = v;
+        mx = fmaxf(mx, v);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float mn = fmaxf(m, mx);
+    const float msafe = (mn == -INFINITY) ? 0.f : mn;
+    const float alpha = __expf(m - msafe);
+    m = mn;
+    float rs = 0.f;
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float pr = __expf(st[sub][r] - msafe);
+        st[sub][r] = pr;
+        rs += pr;
+      }
+    rs += __shfl_xor(rs, 32);
+    l = l * alpha + rs;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+      if (sub == 1 && !sub1) continue;   // its P is exactly zero (every key masked)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = 32 * sub + (r & 3) + 8 * (r >> 2) + 4 * half;   // row of the V tile this lane's k-slot contracts
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+          o[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(Vs[tile_off(key, 32 * dt + l31)], st[sub][r], o[dt], 0, 0, 0);
+      }
+    }
+  }
+  if (query < S) {
+    const float inv = 1.0f / l;
+    float* orow = out + ((size_t)b * S + query) * D + h * HD + 4 * half;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const f32x4 v = {o[dt][4 * j] * inv, o[dt][4 * j + 1] * inv, o[dt][4 * j + 2] * inv, o[dt][4 * j + 3] * inv};
+        *reinterpret_cast<f32x4*>(orow + 32 * dt + 8 * j) = v;
+      }
+    if (half == 0) lse[(size_t)bh * S + query] = m + __logf(l);
+  }
+}
+
 // ------------------------------------------------------------------------------------------- backward: dQ
 // also writes delta[bh, row] = sum_d dO * O for the dK/dV kernel
 template <bool CAUSAL>
@@ -783,6 +902,13 @@ int launch_fwd(const AttnArgs& a, float* out, float* lse, int B, int causal, hip
       default: launch_fwd_rows<5>(a, out, lse, B, causal, st); break;
     }
     DCLIP_CHECK_LAUNCH("attention_fwd.rows");
+    return DCLIP_OK;
+  }
+  if (a.Sq == a.Sk && !a.q_rows && !getenv("DCLIP_ATTN_TILED")) {   // long self-attention: streamed, P in registers
+    dim3 g2(B * a.H, cdiv(a.Sq, 128));
+    if (causal) hipLaunchKernelGGL((attn_fwd_stream_kernel<true>), g2, dim3(256), 0, st, a, out, lse);
+    else hipLaunchKernelGGL((attn_fwd_stream_kernel<false>), g2, dim3(256), 0, st, a, out, lse);
+    DCLIP_CHECK_LAUNCH("attention_fwd.stream");
     return DCLIP_OK;
   }
   dim3 grid(B * a.H, cdiv(a.Sq, TS)), block(256);

@@ -61,3 +61,17 @@ for name, B, S, H, causal in [("regions B/32", 2048, 50, 12, False), ("L/14", 64
     b = t(lambda: ops.attention_fwd_bf16(q16, B, S, H, causal))
     fl = 4.0 * S * S * 64 * B * H
     print(f"{name}: fp32 {a:.1f} us ({fl / a / 1e6:.0f} TF/s) | bf16 {b:.1f} us ({fl / b / 1e6:.0f} TF/s)", flush=True)
+
+print("--- fp32 forward, long sequences: streamed kernel vs tiled")
+for name, B, S, H, causal in [("B/16", 128, 197, 12, False), ("L/14", 64, 257, 16, False), ("causal 130", 64, 130, 8, True)]:
+    qkv = torch.randn(B * S, 3 * H * 64, device=dev)
+    os.environ.pop("DCLIP_ATTN_TILED", None)
+    a = t(lambda: ops.attention_fwd(qkv, B, S, H, causal))
+    o1, l1 = ops.attention_fwd(qkv, B, S, H, causal)
+    os.environ["DCLIP_ATTN_TILED"] = "1"
+    b = t(lambda: ops.attention_fwd(qkv, B, S, H, causal))
+    o2, l2 = ops.attention_fwd(qkv, B, S, H, causal)
+    os.environ.pop("DCLIP_ATTN_TILED", None)
+    fl = 4.0 * S * S * 64 * B * H
+    print(f"{name}: streamed {a:.1f} us ({fl / a / 1e6:.0f} TF/s) | tiled {b:.1f} us | max diff {float((o1 - o2).abs().max()):.2e} "
+          f"lse {float((l1 - l2).abs().max()):.2e}", flush=True)
