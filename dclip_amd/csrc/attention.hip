@@ -623,6 +623,214 @@ __global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(AttnArgs a, const flo
   }
 }
 
+// ------------------------------------------------------------------------------------------- backward, streamed
+// Long self-attention (Sq == Sk > 80): the two-kernel split of the tiled path (dQ by query blocks; dK, dV by key
+// blocks; no atomics) with the register discipline of attn_fwd_stream_kernel — every score / dP block is formed on
+// v_mfma_f32_32x32x2_f32 directly in the layout its consumer contracts over, so P and dS never touch LDS.
+
+// dQ for 32 queries per wave: S^T = K Q^T and dP^T = V dO^T (lane = query column), dS^T in registers is the B operand
+// of dQ^T = K^T dS^T.  Also writes delta[bh, q] = sum_d O dO for the dK/dV kernel.
+template <bool CAUSAL>
+__global__ void __launch_bounds__(256) attn_bwd_dq_stream_kernel(AttnArgs a, const float* __restrict__ out,
+                                                                 const float* __restrict__ dout, const float* __restrict__ lse,
+                                                                 float* __restrict__ dq_out, int lddq, float* __restrict__ delta) {
+  __shared__ __attribute__((aligned(16))) float lds[2 * TS * HD];
+  float* Ks = lds;
+  float* Vs = lds + TS * HD;
+  const int H = a.H, S = a.Sk;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l31 = lane & 31, half = lane >> 5;
+  const int bh = blockIdx.x, b = bh / H, h = bh % H;
+  const int D = H * HD;
+  const int q0 = blockIdx.y * 128 + wave * 32;
+  const int query = q0 + l31, qc = min(query, S - 1);
+  const float* kbase = a.k + (size_t)b * S * a.ldkv + h * HD;
+  const float* vbase = a.v + (size_t)b * S * a.ldkv + h * HD;
+  f32x4 qf[8], dof[8];
+  float my_dl = 0.f;
+  {
+    const float* qrow = a.q + ((size_t)b * S + qc) * a.ldq + h * HD + 4 * half;
+    const float* drow = dout + ((size_t)b * S + qc) * D + h * HD + 4 * half;
+    const float* orow = out + ((size_t)b * S + qc) * D + h * HD + 4 * half;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+      qf[g] = *reinterpret_cast<const f32x4*>(qrow + 8 * g);
+      dof[g] = *reinterpret_cast<const f32x4*>(drow + 8 * g);
+      const f32x4 o4 = *reinterpret_cast<const f32x4*>(orow + 8 * g);
+      my_dl += (o4[0] * dof[g][0] + o4[1] * dof[g][1]) + (o4[2] * dof[g][2] + o4[3] * dof[g][3]);
+    }
+  }
+  my_dl += __shfl_xor(my_dl, 32);
+  const float my_lse = lse[(size_t)bh * S + qc];
+  if (half == 0 && query < S) delta[(size_t)bh * S + query] = my_dl;
+  f32x16 dq[2];
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dq[dt][r] = 0.f;
+  const bool wave_live = q0 < S;
+  int nkt = (S + TS - 1) / TS;
+  if (CAUSAL) nkt = min(nkt, (int)(blockIdx.y * 128 + 127) / TS + 1);
+  for (int kt = 0; kt < nkt; ++kt) {
+    if (kt > 0) __syncthreads();
+    stage_tile(Ks, kbase, kt * TS, S, (size_t)a.ldkv);
+    stage_tile(Vs, vbase, kt * TS, S, (size_t)a.ldkv);
+    __syncthreads();
+    if (!wave_live || (CAUSAL && kt * TS > q0 + 31)) continue;
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+      if (kt * TS + 32 * sub >= S || (CAUSAL && kt * TS + 32 * sub > q0 + 31)) continue;   // wave-uniform
+      f32x16 st, dpt;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        st[r] = 0.f;
+        dpt[r] = 0.f;
+      }
+      const int krow = 32 * sub + l31;
+#pragma unroll
+      for (int g = 0; g < 8; ++g) {
+        const int off = krow * HD + (((2 * g + half) ^ (krow & 15)) << 2);
+        const f32x4 kf = *reinterpret_cast<const f32x4*>(Ks + off);
+        const f32x4 vf = *reinterpret_cast<const f32x4*>(Vs + off);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          st = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[r], qf[g][r], st, 0, 0, 0);
+          dpt = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[r], dof[g][r], dpt, 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = kt * TS + 32 * sub + (r & 3) + 8 * (r >> 2) + 4 * half;
+        const bool masked = key >= S || (CAUSAL && key > query);
+        const float pr = masked ? 0.f : __expf(st[r] * kScale - my_lse);
+        st[r] = pr * (dpt[r] - my_dl) * kScale;   // dS^T
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = 32 * sub + (r & 3) + 8 * (r >> 2) + 4 * half;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+          dq[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(Ks[tile_off(key, 32 * dt + l31)], st[r], dq[dt], 0, 0, 0);
+      }
+    }
+  }
+  if (query < S) {
+    float* o = dq_out + ((size_t)b * S + query) * lddq + h * HD + 4 * half;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        *reinterpret_cast<f32x4*>(o + 32 * dt + 8 * j) = f32x4{dq[dt][4 * j], dq[dt][4 * j + 1], dq[dt][4 * j + 2], dq[dt][4 * j + 3]};
+  }
+}
+
+// dK, dV for 32 keys per wave: S = Q K^T and dP = dO V^T with lane = key column and the queries
+// {(r&3) + 8(r>>2) + 4 half} of a 32-query block in registers: P and dS are the B operands of dV^T = dO^T P and
+// dK^T = Q^T dS.  Q / dO tiles (64 queries) stream through LDS with their lse and delta.
+template <bool CAUSAL>
+__global__ void __launch_bounds__(256) attn_bwd_dkv_stream_kernel(AttnArgs a, const float* __restrict__ dout,
+                                                                  const float* __restrict__ lse, const float* __restrict__ delta,
+                                                                  float* __restrict__ dk_out, float* __restrict__ dv_out,
+                                                                  int lddkv) {
+  __shared__ __attribute__((aligned(16))) float lds[2 * TS * HD + 2 * TS];
+  float* Qs = lds;
+  float* dOs = lds + TS * HD;
+  float* lse_s = lds + 2 * TS * HD;
+  float* dl_s = lse_s + TS;
+  const int H = a.H, S = a.Sk;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l31 = lane & 31, half = lane >> 5;
+  const int bh = blockIdx.x, b = bh / H, h = bh % H;
+  const int D = H * HD;
+  const int k0 = blockIdx.y * 128 + wave * 32;
+  const int key = k0 + l31, kc = min(key, S - 1);
+  const float* qbase = a.q + (size_t)b * S * a.ldq + h * HD;
+  const float* dobase = dout + (size_t)b * S * D + h * HD;
+  f32x4 kf[8], vf[8];
+  {
+    const float* krow = a.k + ((size_t)b * S + kc) * a.ldkv + h * HD + 4 * half;
+    const float* vrow = a.v + ((size_t)b * S + kc) * a.ldkv + h * HD + 4 * half;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+      kf[g] = *reinterpret_cast<const f32x4*>(krow + 8 * g);
+      vf[g] = *reinterpret_cast<const f32x4*>(vrow + 8 * g);
+    }
+  }
+  f32x16 dk[2], dv[2];
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      dk[dt][r] = 0.f;
+      dv[dt][r] = 0.f;
+    }
+  const bool wave_live = k0 < S;
+  const int nqt = (S + TS - 1) / TS;
+  const int qt0 = CAUSAL ? (int)(blockIdx.y * 128) / TS : 0;   // queries before the workgroup's first key see none of its keys
+  for (int qt = qt0; qt < nqt; ++qt) {
+    if (qt > qt0) __syncthreads();
+    stage_tile(Qs, qbase, qt * TS, S, (size_t)a.ldq);
+    stage_tile(dOs, dobase, qt * TS, S, (size_t)D);
+    if (threadIdx.x < TS) {
+      const int q = qt * TS + threadIdx.x;
+      lse_s[threadIdx.x] = q < S ? lse[(size_t)bh * S + q] : 0.f;
+      dl_s[threadIdx.x] = q < S ? delta[(size_t)bh * S + q] : 0.f;
+    }
+    __syncthreads();
+    if (!wave_live || (CAUSAL && qt * TS + 63 < k0)) continue;
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+      if (qt * TS + 32 * sub >= S || (CAUSAL && qt * TS + 32 * sub + 31 < k0)) continue;   // wave-uniform
+      f32x16 s2, dp2;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        s2[r] = 0.f;
+        dp2[r] = 0.f;
+      }
+      const int qrow = 32 * sub + l31;
+#pragma unroll
+      for (int g = 0; g < 8; ++g) {
+        const int off = qrow * HD + (((2 * g + half) ^ (qrow & 15)) << 2);
+        const f32x4 qf = *reinterpret_cast<const f32x4*>(Qs + off);
+        const f32x4 df = *reinterpret_cast<const f32x4*>(dOs + off);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          s2 = __builtin_amdgcn_mfma_f32_32x32x2f32(qf[r], kf[g][r], s2, 0, 0, 0);
+          dp2 = __builtin_amdgcn_mfma_f32_32x32x2f32(df[r], vf[g][r], dp2, 0, 0, 0);
+        }
+      }
+      f32x16 pr;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ql = 32 * sub + (r & 3) + 8 * (r >> 2) + 4 * half;   // query row inside the tile
+        const int q = qt * TS + ql;
+        const bool masked = q >= S || key >= S || (CAUSAL && key > q);
+        pr[r] = masked ? 0.f : __expf(s2[r] * kScale - lse_s[ql]);
+        s2[r] = pr[r] * (dp2[r] - dl_s[ql]) * kScale;   // dS
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ql = 32 * sub + (r & 3) + 8 * (r >> 2) + 4 * half;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          dv[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(dOs[tile_off(ql, 32 * dt + l31)], pr[r], dv[dt], 0, 0, 0);
+          dk[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(Qs[tile_off(ql, 32 * dt + l31)], s2[r], dk[dt], 0, 0, 0);
+        }
+      }
+    }
+  }
+  if (key < S) {
+    const size_t o = ((size_t)b * S + key) * lddkv + h * HD + 4 * half;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        *reinterpret_cast<f32x4*>(dk_out + o + 32 * dt + 8 * j) = f32x4{dk[dt][4 * j], dk[dt][4 * j + 1], dk[dt][4 * j + 2], dk[dt][4 * j + 3]};
+        *reinterpret_cast<f32x4*>(dv_out + o + 32 * dt + 8 * j) = f32x4{dv[dt][4 * j], dv[dt][4 * j + 1], dv[dt][4 * j + 2], dv[dt][4 * j + 3]};
+      }
+  }
+}
+
 // ------------------------------------------------------------------------------------------- backward, one tile
 // Self-attention with S <= 64 (ViT-B/32: S = 50): the whole (batch, head) problem is one tile, so S/P/dP/dS are
 // formed ONCE and dQ, dK, dV all come out of one workgroup — 5 MFMA products instead of the 7 of the two-kernel
@@ -935,6 +1143,16 @@ int launch_bwd(const AttnArgs& a, const float* out, const float* dout, const flo
     if (causal) hipLaunchKernelGGL((attn_bwd_fused_kernel<true>), dim3(B * a.H), block, 0, st, a, out, dout, lse, dq, dk, dv, lddq);
     else hipLaunchKernelGGL((attn_bwd_fused_kernel<false>), dim3(B * a.H), block, 0, st, a, out, dout, lse, dq, dk, dv, lddq);
     DCLIP_CHECK_LAUNCH("attention_bwd.fused");
+    return DCLIP_OK;
+  }
+  if (a.Sq == a.Sk && !a.q_rows && !causal && !getenv("DCLIP_ATTN_TILED")) {
+    // long non-causal self-attention (ViT-B/16, ViT-L/14): streamed kernels, P / dS in registers.  Measured at B/16
+    // (128 x 197 tokens, 12 heads) 1160 vs 1486 us, at L/14 1383 vs 1460 us; a causal 130-token case was slower
+    // (196 vs 177 us), and no configuration has a causal sequence above 80 tokens, so causal stays on the tiled path.
+    dim3 g2(B * a.H, cdiv(a.Sq, 128));
+    hipLaunchKernelGGL((attn_bwd_dq_stream_kernel<false>), g2, block, 0, st, a, out, dout, lse, dq, lddq, delta);
+    hipLaunchKernelGGL((attn_bwd_dkv_stream_kernel<false>), g2, block, 0, st, a, dout, lse, delta, dk, dv, lddkv);
+    DCLIP_CHECK_LAUNCH("attention_bwd.stream");
     return DCLIP_OK;
   }
   if (causal) {

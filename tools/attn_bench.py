@@ -75,3 +75,19 @@ for name, B, S, H, causal in [("B/16", 128, 197, 12, False), ("L/14", 64, 257, 1
     fl = 4.0 * S * S * 64 * B * H
     print(f"{name}: streamed {a:.1f} us ({fl / a / 1e6:.0f} TF/s) | tiled {b:.1f} us | max diff {float((o1 - o2).abs().max()):.2e} "
           f"lse {float((l1 - l2).abs().max()):.2e}", flush=True)
+
+print("--- fp32 backward, long sequences: streamed kernels vs tiled")
+for name, B, S, H, causal in [("B/16", 128, 197, 12, False), ("L/14", 64, 257, 16, False), ("causal 130", 64, 130, 8, True)]:
+    qkv = torch.randn(B * S, 3 * H * 64, device=dev)
+    os.environ.pop("DCLIP_ATTN_TILED", None)
+    o, l = ops.attention_fwd(qkv, B, S, H, causal)
+    do = torch.randn_like(o)
+    a = t(lambda: ops.attention_bwd(qkv, o, do, l, B, S, H, causal))
+    g1 = ops.attention_bwd(qkv, o, do, l, B, S, H, causal)
+    os.environ["DCLIP_ATTN_TILED"] = "1"
+    b = t(lambda: ops.attention_bwd(qkv, o, do, l, B, S, H, causal))
+    g2 = ops.attention_bwd(qkv, o, do, l, B, S, H, causal)
+    os.environ.pop("DCLIP_ATTN_TILED", None)
+    fl = 10.0 * S * S * 64 * B * H
+    print(f"{name}: streamed {a:.1f} us ({fl / a / 1e6:.0f} TF/s algorithmic) | tiled {b:.1f} us | max rel diff "
+          f"{float((g1 - g2).abs().max() / g2.abs().max()):.2e}", flush=True)
