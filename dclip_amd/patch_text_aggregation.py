@@ -290,11 +290,9 @@ class CLIPPatchTokenizer:
             bx = torch.tensor(flat, dtype=torch.int32)
             crops = ops.crop_resize(images_u8, dims, bx.to(dev), s, int((bx[:, 4] - bx[:, 2]).max()),
                                     int((bx[:, 3] - bx[:, 1]).max()))
-            o = 0
-            for b, n in enumerate(counts):
-                if n:
-                    regions[b, :n] = crops[o:o + n]
-                    o += n
+            # one scatter for the whole batch (flat slot b*rmax + r of crop number i), not one copy per image
+            slots = [b * rmax + r for b, n in enumerate(counts) for r in range(n)]
+            regions.view(B * rmax, 3, s, s).index_copy_(0, torch.tensor(slots, dtype=torch.int64, device=dev), crops)
         return regions, torch.tensor(counts, dtype=torch.int32)
 
     @torch.no_grad()
