@@ -199,7 +199,7 @@ class CLIPTextTokenizer:
     def device(self):
         return next(self.model.parameters()).device
 
-    def _ids(self, text) -> torch.Tensor:
+    def _ids(self, text, keep_host: bool = False) -> torch.Tensor:
         if isinstance(text, torch.Tensor):
             ids = text if text.dim() == 2 else text.unsqueeze(0)
         else:
@@ -207,7 +207,8 @@ class CLIPTextTokenizer:
                 raise RuntimeError("caption strings need a CLIPTokenizer (load one from a local path); "
                                    "or pass token ids")
             ids = self.tokenizer(text, return_tensors="pt", padding=True, truncation=True, max_length=77).input_ids
-        return ids.to(self.device).long().contiguous()
+        ids = ids.long().contiguous()
+        return ids if keep_host else ids.to(self.device)
 
     @torch.no_grad()
     def token_level_ids(self, input_ids: torch.Tensor):
@@ -418,5 +419,13 @@ class PatchTextAggregation(nn.Module):
                 except Exception:
                     images.append(Image.new("RGB", (224, 224)))        # the reference's fallback (:302)
         regions, counts = self.patch_tokenizer.crop_boxes_gpu(images, boxes, images_u8, dims)
-        ids = self.text_tokenizer._ids(texts if isinstance(texts, torch.Tensor) else list(texts))
-        return self.compute_global_embedding_tensors(regions, ids, counts)
+        ids = self.text_tokenizer._ids(texts if isinstance(texts, torch.Tensor) else list(texts), keep_host=True)
+        max_tokens = None
+        if not ids.is_cuda:
+            # token ids still on the host (tokenizer output): the longest caption's word-token count is known without
+            # asking the GPU — no stream synchronisation in the middle of the step
+            eos_id = self._clip.config.text.eos_token_id
+            first_eos = (ids == eos_id).int().argmax(dim=1)
+            max_tokens = max(int(first_eos.max()) - 1, 1)
+            ids = ids.to(self.device)
+        return self.compute_global_embedding_tensors(regions, ids, counts, max_tokens)

@@ -343,7 +343,7 @@ def test_teacher_path_based_signature(dev, tmp_path):
         paths.append(p)
         boxes.append([((4 * r, 2 * r, 50 + 4 * r, 40 + 2 * r), 0.9) for r in range(b)])     # 0, 1, 2 boxes
     ids = synth.synth_input_ids(3, cfg.text, seed=9, ragged=True, min_len=4)
-    teacher.text_tokenizer._ids = lambda texts: ids.to(dev)                                  # no BPE vocab offline
+    teacher.text_tokenizer._ids = lambda texts, keep_host=False: ids if keep_host else ids.to(dev)   # no BPE vocab offline
     got = teacher.compute_global_embedding_batch(paths, ["a", "b", "c"], boxes)
     crops = torch.zeros(3, 2, 3, cfg.vision.image_size, cfg.vision.image_size)
     for b in range(3):
