@@ -116,10 +116,11 @@ class CLIPImageDistillation(LightningLikeModule):
         if isinstance(batch, dict) and "captions" in batch:
             # data.GpuCollate: decoded images already on the device, student preprocessing done there
             images = batch["pixel_values"].to(dev)
-            tokens = self._tokenize(batch["captions"]).to(dev)
+            host_tokens = self._tokenize(batch["captions"])
+            tokens = host_tokens.to(dev, non_blocking=True)
             with torch.no_grad():
                 teacher_image = self.teacher.compute_global_embedding_batch(
-                    batch["image_paths"], tokens, batch["weighted_boxes"], batch.get("images_u8"),
+                    batch["image_paths"], host_tokens, batch["weighted_boxes"], batch.get("images_u8"),
                     batch.get("dims")).to(dev).float()
             teacher_text = None
         elif isinstance(batch, dict):
@@ -134,11 +135,13 @@ class CLIPImageDistillation(LightningLikeModule):
                 teacher_text = batch["teacher_text_emb"].to(dev).float() if "teacher_text_emb" in batch else None
         else:
             images, captions, image_paths, weighted_boxes_batch = batch
-            images = images.to(dev)
-            tokens = self._tokenize(captions).to(dev)
+            images = images.to(dev, non_blocking=True)        # pinned by the DataLoader (pin_memory=True, :687)
+            host_tokens = self._tokenize(captions)
+            tokens = host_tokens.to(dev, non_blocking=True)
             with torch.no_grad():
+                # the teacher gets the HOST ids: it sizes its token padding from them without a stream sync
                 teacher_image = self.teacher.compute_global_embedding_batch(
-                    image_paths, captions, weighted_boxes_batch).to(dev).float()
+                    image_paths, host_tokens, weighted_boxes_batch).to(dev).float()
             teacher_text = None
         student_image = self.student.get_image_features(pixel_values=images).float()
         loss_image = self.cosine_distillation_loss(student_image, teacher_image)
