@@ -143,3 +143,76 @@ def test_trainer_with_hip_graph_matches_eager_trainer():
     assert a.keys() == b.keys()
     for n in a:
         assert torch.allclose(a[n], b[n], rtol=1e-5, atol=1e-7), (n, float((a[n] - b[n]).abs().max()))
+
+
+def test_reference_batch_format_end_to_end(tmp_path):
+    """The reference's own data path: JSON + image files + pickled box cache -> MultiModalDataset -> DataLoader with
+    custom_collate_fn -> (images, captions, paths, boxes) tuples -> training_step -> Trainer.fit; and the GpuCollate
+    variant of the same batch gives the same loss."""
+    import json, pickle
+    from PIL import Image
+    from dclip_amd import data
+    from dclip_amd.CLIP_image_distillation import CLIPImageDistillation
+    from dclip_amd.clip_model import from_hf_state_dict
+    from dclip_amd.lightning_lite import Trainer
+    from dclip_amd.patch_text_aggregation import PatchTextAggregation
+    dev = torch.device("cuda:0")
+    cfg = dcfg.tiny(image_size=64, patch_size=16)
+    T = cfg.text.max_position_embeddings
+
+    class ToyTok:                                                   # no BPE vocabulary offline
+        def __call__(self, text, return_tensors="pt", padding=True, truncation=True, max_length=77, **kw):
+            caps = [text] if isinstance(text, str) else list(text)
+            rows = [[cfg.text.bos_token_id] + [1 + (sum(map(ord, w)) % (cfg.text.bos_token_id - 2)) for w in c.split()][:T - 2]
+                    + [cfg.text.eos_token_id] for c in caps]
+            L = max(len(r) for r in rows)                           # padding=True: to the longest caption of the batch
+            ids = torch.full((len(rows), L), cfg.text.eos_token_id, dtype=torch.int64)
+            for b, r in enumerate(rows):
+                ids[b, :len(r)] = torch.tensor(r)
+            return type("Enc", (dict,), {"input_ids": property(lambda s: s["input_ids"])})(input_ids=ids)
+
+    tok = ToyTok()
+    pre = data.ClipImagePreprocess(size=64, tokenizer=tok)
+    recs, cache = [], {}
+    rs = __import__("numpy").random.RandomState(0)
+    for i in range(8):
+        p = tmp_path / f"im{i}.png"
+        h, w = 70 + 5 * i, 90 + 3 * i
+        Image.fromarray(synth.synth_photo(h, w, seed=40 + i)).save(p)
+        recs.append({"image_path": str(p), "captions": [f"photo of thing number {i} in a field", f"thing {i}"]})
+        cache[str(p)] = [((int(rs.randint(0, 30)), int(rs.randint(0, 20)), int(rs.randint(40, w)), int(rs.randint(30, h))), 0.9)
+                         for _ in range(i % 3)]
+    (tmp_path / "train.json").write_text(json.dumps(recs))
+    (tmp_path / "cache").mkdir()
+    with open(tmp_path / "cache" / "train_precache.pkl", "wb") as f:
+        pickle.dump(cache, f, protocol=4)
+
+    def module():
+        clip = from_hf_state_dict(cfg, synth.synth_clip_state_dict(cfg, seed=7, gain=3.0), device=dev)
+        teacher = PatchTextAggregation(embed_dim=cfg.projection_dim, num_heads=1, clip_model=clip, tokenizer=tok).to(dev)
+        hp = argparse.Namespace(train_file=str(tmp_path / "train.json"), val_file=None, train_batch_size=4, eval_batch_size=4,
+                                learning_rate=1e-3, warmup_steps=0, total_steps=100, cache_dir=str(tmp_path / "cache"))
+        return CLIPImageDistillation(hp, clip, pre, teacher=teacher).to(dev)
+
+    import random
+    m = module()
+    random.seed(5)
+    loader = m.train_dataloader()
+    batch = next(iter(loader))
+    assert isinstance(batch, tuple) and batch[0].shape == (4, 3, 64, 64) and len(batch[3]) == 4
+    loss_host = m.training_step(batch)
+    assert bool(torch.isfinite(loss_host))
+    # same four samples through the GPU collate: decode only on the host, preprocessing + crops from one upload
+    ds = data.MultiModalDataset(str(tmp_path / "train.json"), pre, cache_dir=str(tmp_path / "cache"), decode_only=True)
+    idx = [next(i for i, r in enumerate(recs) if r["image_path"] == p) for p in batch[2]]
+    items = []
+    for i, cap in zip(idx, batch[1]):
+        arr, _, path, boxes = ds[i]
+        items.append((arr, cap, path, boxes))                      # keep the caption the host loader drew
+    gb = data.GpuCollate(dev, size=64)(items)
+    loss_gpu = m.training_step(gb)
+    assert torch.equal(loss_host.detach(), loss_gpu.detach())
+    # and the loop itself: two optimiser steps over the loader change the trainable parameters
+    before = m.student.visual_projection.weight.detach().clone()
+    Trainer(max_epochs=1, gradient_clip_val=0.5, accumulate_grad_batches=1).fit(m)
+    assert not torch.equal(before, m.student.visual_projection.weight.detach())
