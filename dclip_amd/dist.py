@@ -117,10 +117,9 @@ class GradSync:
         self._launch()
         for work, flat, layout in self._inflight:
             work.wait()
-            dst = [p.grad for p, _, _ in layout if p.grad is not None]
-            src = [flat[o:o + n].view_as(p.grad) for p, o, n in layout if p.grad is not None]
-            if dst:
-                torch._foreach_copy_(dst, src)            # one multi-tensor copy back into the .grad fields
+            for p, o, n in layout:                        # zero-copy: .grad becomes a view of the reduced bucket
+                if p.grad is not None:
+                    p.grad = flat[o:o + n].view_as(p)
         self._inflight, self._seen = [], set()
 
     reduce = finish
