@@ -37,6 +37,7 @@ struct GemmParams {
   int k_per_split;  // multiple of BK
   float* slab;      // split-K partials [split][M][N] or nullptr
   float* rs_slab;   // A_ROWSUM under split-K: partials [split][M]
+  int group_m;      // tile rows per rasterisation group (8: an XCD's ~96 co-resident tiles cover a compact patch)
   // contrastive-loss modes (mode 0 = plain GEMM)
   int mode;              // 1: row-LSE partials over this tile's columns, 2: dZ tile, 3: per-row count of z > lse_row[row]
   const float* lse_row;  // mode 2
@@ -93,7 +94,7 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) gemm_f32_kernel(GemmParams p)
   // Each XCD walks a contiguous range of `swz`; inside it tiles are visited in groups of GROUP_M tile-rows, column
   // by column, so the ~64 workgroups resident on one XCD cover an ~8x8 patch of tiles: every A / B panel slice
   // fetched into that XCD's L2 is shared by 8 tiles (fabric reads ~ |A|*tiles_n/8 + |B|*tiles_m/8).
-  constexpr int GROUP_M = 8;
+  const int GROUP_M = p.group_m;
   const int swz = xcd_remap(blockIdx.x, nwg);
   const int per_group = GROUP_M * p.tiles_n;
   const int first_m = (swz / per_group) * GROUP_M;
@@ -570,6 +571,11 @@ int launch_cfg(const GemmParams& p, int layout, int splits, hipStream_t st) {
 
 constexpr int NUM_CU = 256;
 
+inline int group_m_default() {
+  static const int g = getenv("DCLIP_GEMM_GROUP_M") ? atoi(getenv("DCLIP_GEMM_GROUP_M")) : 8;   // tuning aid
+  return g > 0 ? g : 8;
+}
+
 struct Plan {
   int bm, bn, splits, k_per_split;
 };
@@ -650,7 +656,7 @@ DCLIP_API int dclip_gemm_f32(const float* A, const float* B, float* C, const flo
   DCLIP_REQUIRE((double)128 * (ak ? lda : 1) * 4.0 < 2147483647.0 && (double)128 * (bk ? ldb : 1) * 4.0 < 2147483647.0,
                 "gemm_f32: leading dimension too large");
   GemmParams p{A, B, C, bias, residual, aux, M, N, K, lda, ldb, ldc, epilogue, alpha,
-               cdiv(M, pl.bm), cdiv(N, pl.bn), pl.k_per_split, nullptr, nullptr,
+               cdiv(M, pl.bm), cdiv(N, pl.bn), pl.k_per_split, nullptr, nullptr, group_m_default(),
                MODE_GEMM, nullptr, nullptr, nullptr, nullptr, 0, nullptr};
   if (pl.splits > 1) {
     const size_t need = (size_t)pl.splits * ((size_t)M * N + M) * sizeof(float);
@@ -736,7 +742,7 @@ DCLIP_API int dclip_contrastive_lse(const float* a_local, const float* b_global,
   float* pm = (float*)workspace;
   float* ps = pm + slots * Bl;
   GemmParams p{a_local, b_global, nullptr, nullptr, nullptr, nullptr, Bl, Bg, P, P, P, 0, 0, inv_temp,
-               cdiv(Bl, LOSS_BM), cdiv(Bg, LOSS_BN), cdiv(P, BK) * BK, nullptr, nullptr,
+               cdiv(Bl, LOSS_BM), cdiv(Bg, LOSS_BN), cdiv(P, BK) * BK, nullptr, nullptr, 8,
                MODE_LSE, nullptr, nullptr, pm, ps, offset, nullptr};
   hipStream_t st = (hipStream_t)stream;
   launch_cfg<LOSS_BM, LOSS_BN, 2, LOSS_WN>(p, DCLIP_A_KMAJOR | DCLIP_B_KMAJOR, 1, st);
@@ -761,7 +767,7 @@ DCLIP_API int dclip_contrastive_grad(const float* a_local, const float* b_global
   hipStream_t st = (hipStream_t)stream;
   // W[i,j] = exp(z_ij - lse_row[i]) + exp(z_ij - lse_col[j]) - 2[j == i+offset]
   GemmParams p{a_local, b_global, W, nullptr, nullptr, nullptr, Bl, Bg, P, P, P, ldw, 0, inv_temp,
-               cdiv(Bl, LOSS_BM), cdiv(Bg, LOSS_BN), cdiv(P, BK) * BK, nullptr, nullptr,
+               cdiv(Bl, LOSS_BM), cdiv(Bg, LOSS_BN), cdiv(P, BK) * BK, nullptr, nullptr, 8,
                MODE_DZ, lse_row, lse_col, nullptr, nullptr, offset, nullptr};
   launch_cfg<LOSS_BM, LOSS_BN, 2, LOSS_WN>(p, DCLIP_A_KMAJOR | DCLIP_B_KMAJOR, 1, st);
   DCLIP_CHECK_LAUNCH("contrastive_grad.dz");
@@ -824,7 +830,7 @@ DCLIP_API int dclip_rank_count(const float* queries, const float* candidates, co
   }
   float* part = (float*)workspace;
   GemmParams p{queries, candidates, nullptr, nullptr, nullptr, nullptr, Bq, Bk, P, P, P, 0, 0, 1.0f,
-               cdiv(Bq, LOSS_BM), cdiv(Bk, LOSS_BN), cdiv(P, BK) * BK, nullptr, nullptr,
+               cdiv(Bq, LOSS_BM), cdiv(Bk, LOSS_BN), cdiv(P, BK) * BK, nullptr, nullptr, 8,
                MODE_RANK, thresh, nullptr, nullptr, part, 0, gt};
   hipStream_t st = (hipStream_t)stream;
   launch_cfg<LOSS_BM, LOSS_BN, 2, LOSS_WN>(p, DCLIP_A_KMAJOR | DCLIP_B_KMAJOR, 1, st);
