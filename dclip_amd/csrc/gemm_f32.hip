@@ -71,7 +71,13 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   return base + i;
 }
 
-template <int BM, int BN, int WM, int WN, bool A_KMAJOR, bool B_KMAJOR>
+// 16 bytes per lane, global -> LDS without passing through registers (lane i lands at lds_dst + 16 i).  A __device__
+// function on purpose: with the builtin in a lambda of the kernel template hipcc 7.2 drops the template's host stub.
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, float* lds_dst, int voff, int soff) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_dst, 16, voff, soff, 0, 0);
+}
+
+template <int BM, int BN, int WM, int WN, bool A_KMAJOR, bool B_KMAJOR, bool DMA = false>
 __global__ void __launch_bounds__(WM * WN * 64, 2) gemm_f32_kernel(GemmParams p) {
   constexpr int NTHR = WM * WN * 64;  // 4 waves, or 8 for the 128x128 tile (two 64x32 wave tiles per SIMD)
   constexpr int TM = BM / WM, TN = BN / WN;
@@ -155,6 +161,29 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) gemm_f32_kernel(GemmParams p)
     if (B_KMAJOR) b_voff[c] = (min(id >> 3, b_rows - 1) * p.ldb + (id & 7) * 4) * 4;
     else b_voff[c] = ((id / (BN / 4)) * p.ldb + min((id % (BN / 4)) * 4, p.N - n0 - 4)) * 4;
   }
+
+  // LDS-DMA staging (DMA variants, steady state only): chunk `id` must LAND at linear LDS position id, so for a
+  // swizzled K-major image the lane fetches the logical slot that lives there: (id & 7) ^ ((row >> 1) & 7).
+  int a_dvoff[DMA ? A_CHUNKS : 1], b_dvoff[DMA ? B_CHUNKS : 1];
+  if (DMA) {
+#pragma unroll
+    for (int c = 0; c < A_CHUNKS; ++c) {
+      const int id = tid + c * NTHR, row = id >> 3;
+      a_dvoff[c] = A_KMAJOR ? (min(row, a_rows - 1) * p.lda + (((id & 7) ^ ((row >> 1) & 7)) * 4)) * 4 : a_voff[c];
+    }
+#pragma unroll
+    for (int c = 0; c < B_CHUNKS; ++c) {
+      const int id = tid + c * NTHR, row = id >> 3;
+      b_dvoff[c] = B_KMAJOR ? (min(row, b_rows - 1) * p.ldb + (((id & 7) ^ ((row >> 1) & 7)) * 4)) * 4 : b_voff[c];
+    }
+  }
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  auto dma_chunk = [&](int buf, int kt, int c) {   // chunk c of tile kt -> stage `buf` (A chunks first, then B)
+    if (c < A_CHUNKS) dma16(a_rsrc, As + buf * BM * BK + (wave_u + (NTHR / 64) * c) * 256, a_dvoff[DMA ? c : 0], kt * a_kstep);
+    else
+      dma16(b_rsrc, Bs + buf * BN * BK + (wave_u + (NTHR / 64) * (c - A_CHUNKS)) * 256, b_dvoff[DMA ? c - A_CHUNKS : 0],
+            kt * b_kstep);
+  };
 
   auto load_tile = [&](int kt) {
 #pragma unroll
@@ -309,6 +338,37 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) gemm_f32_kernel(GemmParams p)
     }
   };
 
+  // DMA variant of the steady state: no staging registers, no ds_write (the VGPR -> LDS transfer path moves only
+  // ~79 B/clk/CU and is shared by the three co-resident workgroups) — one DMA piece behind each of MFMA steps
+  // 1..NCH (so every piece has >= 16 - NCH steps to land), then vmcnt(0) and the barrier.  Issuing on every other
+  // step instead measured +0.3 % rather than +1.1 %.
+  auto compute_and_dma = [&](int buf, int kt) {
+    const float* a = As + buf * BM * BK;
+    const float* b = Bs + buf * BN * BK;
+    constexpr int NCH = A_CHUNKS + B_CHUNKS;
+    f32x4 fa[2][MT], fb[2][NT];
+    read_frags(a, b, 0, fa[0], fb[0]);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      if (g + 1 < 4) read_frags(a, b, g + 1, fa[(g + 1) & 1], fb[(g + 1) & 1]);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[g & 1][i][r], fb[g & 1][j][r], acc[i][j], 0, 0, 0);
+        const int step = g * 4 + r;
+        if (step >= 1 && step - 1 < NCH) {
+          __builtin_amdgcn_sched_barrier(0);
+          dma_chunk(buf ^ 1, kt + 1, step - 1);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's pieces of the next tile have landed
+  };
+
   const bool k_ragged = (A_KMAJOR || B_KMAJOR) && (kspan % BK) != 0;  // only the last tile can be partial
   load_tile(0);
   if (k_ragged && nk == 1) store_tile(0, 0, true);
@@ -317,7 +377,8 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) gemm_f32_kernel(GemmParams p)
   int kt = 0;
   const int n_steady = nk - 1 - (k_ragged ? 1 : 0);  // tiles whose successor is a full tile
   for (; kt < n_steady; ++kt) {
-    compute_and_stage(kt & 1, kt);
+    if (DMA && !do_rs) compute_and_dma(kt & 1, kt);   // the row sums need the chunks in registers: tile column 0 keeps them
+    else compute_and_stage(kt & 1, kt);
     __syncthreads();
   }
   for (; kt < nk; ++kt) {
@@ -558,6 +619,17 @@ int launch_cfg(const GemmParams& p, int layout, int splits, hipStream_t st) {
   dim3 grid(p.tiles_m * p.tiles_n, splits);
   const size_t lds = (size_t)2 * (BM + BN) * BK * sizeof(float);
   const bool ak = layout & DCLIP_A_KMAJOR, bk = layout & DCLIP_B_KMAJOR;
+  // LDS-DMA staging for the K-major-A kernels on 128-row tiles (forward and dgrad GEMMs): +1.1 % on the step
+  // (3891 vs 3846 img/s, same box).  Measured slower on the 64x64 [K][M]-major wgrad kernel (-1.2 % with everything
+  // on DMA), which keeps register staging.  DCLIP_GEMM_DMA=0 switches it off (A/B aid).
+  static const bool dma = !(getenv("DCLIP_GEMM_DMA") && atoi(getenv("DCLIP_GEMM_DMA")) == 0);
+  if constexpr (BM == 128 && WM * WN == 4) {
+    if (dma && ak && p.mode == MODE_GEMM) {
+      if (bk) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, true, true, true>), grid, dim3(WM * WN * 64), lds, st, p);
+      else hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, true, false, true>), grid, dim3(WM * WN * 64), lds, st, p);
+      return 0;
+    }
+  }
   if (ak && bk)
     hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, true, true>), grid, dim3(WM * WN * 64), lds, st, p);
   else if (ak && !bk)
