@@ -22,6 +22,33 @@ __global__ void __launch_bounds__(256) im2col_kernel(const float* __restrict__ p
   }
 }
 
+// Vector form for patch sizes that are multiples of 4 (ViT-B/32, ViT-B/16): a thread moves 4 consecutive px — 16 bytes
+// in, 16 bytes (fp32) or 8 bytes (bf16, for the frozen towers' bf16 GEMM) out.  `ldc` = destination row length.
+typedef unsigned short u16x4_e __attribute__((ext_vector_type(4)));
+template <bool OUT_BF16>
+__global__ void __launch_bounds__(256) im2col_vec_kernel(const float* __restrict__ pix, void* __restrict__ cols, int B, int C,
+                                                         int Himg, int Wimg, int p, int g, int ldc, size_t total4) {
+  const int kdim4 = C * p * p / 4, p4 = p / 4;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
+    const int k4 = (int)(i % kdim4);
+    const size_t row = i / kdim4;
+    const int gx = (int)(row % g), gy = (int)((row / g) % g), b = (int)(row / ((size_t)g * g));
+    const int px = (k4 % p4) * 4, py = (k4 / p4) % p, c = k4 / (p4 * p);
+    const f32x4 v = *reinterpret_cast<const f32x4*>(pix + (((size_t)b * C + c) * Himg + gy * p + py) * Wimg + gx * p + px);
+    if (OUT_BF16) {
+      u16x4_e o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        __bf16 h = (__bf16)v[e];
+        o[e] = __builtin_bit_cast(unsigned short, h);
+      }
+      *reinterpret_cast<u16x4_e*>(reinterpret_cast<unsigned short*>(cols) + row * ldc + (size_t)k4 * 4) = o;
+    } else {
+      *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(cols) + row * ldc + (size_t)k4 * 4) = v;
+    }
+  }
+}
+
 __global__ void __launch_bounds__(256) vision_assemble_fwd_kernel(const float* __restrict__ patch, const float* __restrict__ cls,
                                                                   const float* __restrict__ pos, float* __restrict__ x, int B,
                                                                   int S, int D4, size_t total4) {
@@ -121,9 +148,28 @@ DCLIP_API int dclip_im2col(const float* pixels, float* cols, int B, int C, int H
                 Wimg, patch);
   const int g = Himg / patch;
   const size_t total = (size_t)B * g * g * C * patch * patch;
-  hipLaunchKernelGGL(im2col_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, pixels, cols, B, C, Himg, Wimg,
-                     patch, g, total);
+  if (patch % 4 == 0 && ((uintptr_t)pixels | (uintptr_t)cols) % 16 == 0)
+    hipLaunchKernelGGL((im2col_vec_kernel<false>), dim3(grid_for(total / 4)), dim3(256), 0, (hipStream_t)stream, pixels, cols, B,
+                       C, Himg, Wimg, patch, g, C * patch * patch, total / 4);
+  else
+    hipLaunchKernelGGL(im2col_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, pixels, cols, B, C, Himg, Wimg,
+                       patch, g, total);
   DCLIP_CHECK_LAUNCH("im2col");
+  return DCLIP_OK;
+}
+
+DCLIP_API int dclip_im2col_bf16(const float* pixels, void* cols, int B, int C, int Himg, int Wimg, int patch, int ldc,
+                                void* stream) {
+  DCLIP_REQUIRE(pixels && cols, "im2col_bf16: null pointer");
+  DCLIP_REQUIRE(B > 0 && C > 0 && patch > 0 && patch % 4 == 0 && Himg == Wimg && Himg % patch == 0,
+                "im2col_bf16: bad shape %dx%d patch %d (patch must be a multiple of 4)", Himg, Wimg, patch);
+  DCLIP_REQUIRE(ldc >= C * patch * patch && ldc % 4 == 0 && (uintptr_t)pixels % 16 == 0 && (uintptr_t)cols % 8 == 0,
+                "im2col_bf16: ldc / alignment");
+  const int g = Himg / patch;
+  const size_t total4 = (size_t)B * g * g * C * patch * patch / 4;
+  hipLaunchKernelGGL((im2col_vec_kernel<true>), dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)stream, pixels, cols, B, C,
+                     Himg, Wimg, patch, g, ldc, total4);
+  DCLIP_CHECK_LAUNCH("im2col_bf16");
   return DCLIP_OK;
 }
 

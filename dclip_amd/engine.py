@@ -301,7 +301,8 @@ def vision_fwd_bf16(p: VisionParams, pixel_values: torch.Tensor, cfg, cache: dic
     v = cfg
     B = pixel_values.shape[0]
     S, D, H = v.seq_len, v.hidden_size, v.num_attention_heads
-    cols = ops.cast_bf16(ops.im2col(pixel_values, v.patch_size))
+    cols = (ops.im2col_bf16(pixel_values, v.patch_size) if v.patch_size % 4 == 0        # one pass: gather + round
+            else ops.cast_bf16(ops.im2col(pixel_values, v.patch_size)))
     patch = ops.gemm_bf16(cols, _w16(cache, "patch", p.patch_w), k=v.patch_dim)
     x, _, _ = ops.layernorm_fwd(ops.vision_assemble_fwd(patch, p.class_embedding, p.pos, B, S, D), p.pre_w, p.pre_b,
                                 v.layer_norm_eps, save_stats=False)

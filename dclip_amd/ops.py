@@ -250,6 +250,21 @@ def im2col(pixels: torch.Tensor, patch: int) -> torch.Tensor:
     return cols
 
 
+def im2col_bf16(pixels: torch.Tensor, patch: int) -> torch.Tensor:
+    """im2col with a bf16 result (rows padded to a multiple of 8 columns, zero filled); patch % 4 == 0."""
+    lib = _lib.load()
+    _f32(pixels, "pixel_values")
+    B, Cc, Hh, Ww = pixels.shape
+    if Hh != Ww or Hh % patch or patch % 4:
+        raise ValueError(f"im2col_bf16: image {Hh}x{Ww}, patch {patch}")
+    g, kdim = Hh // patch, Cc * patch * patch
+    ld = (kdim + 7) // 8 * 8
+    alloc = torch.zeros if ld != kdim else torch.empty
+    cols = alloc((B * g * g, ld), dtype=torch.bfloat16, device=pixels.device)
+    _lib.check(lib.dclip_im2col_bf16(pixels.data_ptr(), cols.data_ptr(), B, Cc, Hh, Ww, patch, ld, _stream()), "im2col_bf16")
+    return cols
+
+
 def vision_assemble_fwd(patch_emb, cls, pos, B: int, S: int, D: int) -> torch.Tensor:
     lib = _lib.load()
     _f32(patch_emb, "patch_emb"), _f32(cls, "class_embedding"), _f32(pos, "position_embedding")

@@ -144,6 +144,9 @@ int dclip_attention_cls_bwd(const float* qkv, const float* out, const float* dou
  * scatter_rows: its transpose, writing the whole [B,S,D] gradient (zeros off the selected row).
  */
 int dclip_im2col(const float* pixels, float* cols, int B, int C, int Himg, int Wimg, int patch, void* stream);
+/* Same gather with a bf16 destination (row length ldc >= C*patch*patch, multiple of 4; patch % 4 == 0): the A operand
+ * of the frozen towers' bf16 patch-embedding GEMM, written in one pass instead of im2col + cast. */
+int dclip_im2col_bf16(const float* pixels, void* cols, int B, int C, int Himg, int Wimg, int patch, int ldc, void* stream);
 int dclip_vision_assemble_fwd(const float* patch, const float* cls, const float* pos, float* x, int B, int S,
                               int D, void* stream);
 int dclip_vision_assemble_bwd(const float* dx, float* dpatch, int B, int S, int D, void* stream);

@@ -156,3 +156,15 @@ def test_attention_fwd_bf16(B, S, H, causal):
     assert got.dtype == torch.bfloat16 and tuple(got.shape) == (B * S, D)
     err = float((got.double().cpu() - want).abs().max() / want.abs().max())
     assert err < 1.5e-2, err          # bf16 rounding of P (2^-9 relative) and of the output
+
+
+@pytest.mark.parametrize("B,S,p", [(3, 64, 16), (2, 224, 32), (5, 32, 4)])
+def test_im2col_bf16_equals_im2col_then_round(B, S, p):
+    from dclip_amd import ops
+    dev = torch.device("cuda:0")
+    pix = rnd((B, 3, S, S), 11).to(dev)
+    want = ops.im2col(pix, p).to(torch.bfloat16)
+    got = ops.im2col_bf16(pix, p)
+    assert got.dtype == torch.bfloat16 and torch.equal(got[:, :want.shape[1]], want)
+    ref = pix.cpu().unfold(2, p, p).unfold(3, p, p).permute(0, 2, 3, 1, 4, 5).reshape(B * (S // p) ** 2, 3 * p * p)
+    assert torch.equal(ops.im2col(pix, p).cpu(), ref)                    # the vectorised fp32 path
