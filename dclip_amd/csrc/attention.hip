@@ -623,6 +623,143 @@ __global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(AttnArgs a, const flo
   }
 }
 
+// ------------------------------------------------------------------------------------------- backward, one tile, lean
+// S <= 64 (ViT-B/32's 50 tokens), the five-product schedule of attn_bwd_fused_kernel with 48 KiB of LDS instead of
+// 80 KiB (three workgroups per CU instead of two: the fused kernel is latency bound at 1.8 waves per SIMD):
+//   phase A  wave w owns KEYS 16w..16w+15.  K and V own rows come straight from global as B-operand fragments; the
+//            Q and dO tiles are in LDS.  S = Q K^T and dP = dO V^T land as [query 4qd+r][key l15], so P and dS are
+//            the B operands of dV^T = dO^T P and dK^T = Q^T dS without leaving registers; dS is also written to
+//            an LDS tile for phase B.  dK, dV leave as 16-byte stores.
+//   phase B  the K tile is staged over the (now dead) Q tile; wave w owns QUERIES 16w..16w+15 and forms
+//            dQ^T = K^T dS^T with dS^T read as 16-byte runs of its own rows of the dS tile.
+template <bool CAUSAL>
+__global__ void __launch_bounds__(256, 3) attn_bwd_lean_kernel(AttnArgs a, const float* __restrict__ out,
+                                                               const float* __restrict__ dout, const float* __restrict__ lse,
+                                                               float* __restrict__ dq_out, float* __restrict__ dk_out,
+                                                               float* __restrict__ dv_out, int ldd) {
+  __shared__ __attribute__((aligned(16))) float lds[3 * TS * HD + 2 * TS];
+  float* Qs = lds;                 // phase B: the K tile
+  float* dOs = lds + TS * HD;
+  float* dSs = lds + 2 * TS * HD;
+  float* lse_s = lds + 3 * TS * HD;
+  float* dl_s = lse_s + TS;
+  const int H = a.H, S = a.Sk;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int qd = lane >> 4, l15 = lane & 15;
+  const int bh = blockIdx.x, b = bh / H, h = bh % H;
+  const int D = H * HD;
+  const float* qbase = a.q + (size_t)b * S * a.ldq + h * HD;
+  const float* kbase = a.k + (size_t)b * S * a.ldkv + h * HD;
+  const float* vbase = a.v + (size_t)b * S * a.ldkv + h * HD;
+  const float* dobase = dout + (size_t)b * S * D + h * HD;
+  stage_tile(Qs, qbase, 0, S, (size_t)a.ldq);
+  stage_tile(dOs, dobase, 0, S, (size_t)D);
+  const int own = 16 * wave + l15, ownc = min(own, S - 1);
+  // own K / V rows as B-operand fragments: row own, head dims 16g + 4qd .. +3
+  f32x4 kf[4], vf[4];
+  float my_dl = 0.f;
+  {
+    const float* krow = kbase + (size_t)ownc * a.ldkv + 4 * qd;
+    const float* vrow = vbase + (size_t)ownc * a.ldkv + 4 * qd;
+    const float* orow = out + ((size_t)b * S + ownc) * D + h * HD + 4 * qd;
+    const float* drow = dobase + (size_t)ownc * D + 4 * qd;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      kf[g] = *reinterpret_cast<const f32x4*>(krow + 16 * g);
+      vf[g] = *reinterpret_cast<const f32x4*>(vrow + 16 * g);
+      const f32x4 o4 = *reinterpret_cast<const f32x4*>(orow + 16 * g);
+      const f32x4 d4 = *reinterpret_cast<const f32x4*>(drow + 16 * g);
+      my_dl += (o4[0] * d4[0] + o4[1] * d4[1]) + (o4[2] * d4[2] + o4[3] * d4[3]);
+    }
+  }
+  my_dl += __shfl_xor(my_dl, 16);
+  my_dl += __shfl_xor(my_dl, 32);
+  if (qd == 0) {
+    lse_s[own] = own < S ? lse[(size_t)bh * S + own] : 0.f;
+    dl_s[own] = own < S ? my_dl : 0.f;
+  }
+  __syncthreads();
+  const int kts = (S + 15) / 16;
+  // ---- phase A: own keys, every query tile -> dK, dV, and the dS tile
+  {
+    f32x4 dk[4], dv[4];
+    zero4(dk);
+    zero4(dv);
+#pragma unroll
+    for (int qt = 0; qt < 4; ++qt) {
+      const bool live = qt < kts && (!CAUSAL || qt >= wave);   // wave-uniform
+      f32x4 pr = {0.f, 0.f, 0.f, 0.f}, ds = {0.f, 0.f, 0.f, 0.f};
+      if (live) {
+        f32x4 s2 = {0.f, 0.f, 0.f, 0.f}, dp2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 qf = frag_k(Qs, 16 * qt, g, lane);
+          const f32x4 df = frag_k(dOs, 16 * qt, g, lane);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            s2 = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[r], kf[g][r], s2, 0, 0, 0);
+            dp2 = __builtin_amdgcn_mfma_f32_16x16x4f32(df[r], vf[g][r], dp2, 0, 0, 0);
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int q = 16 * qt + 4 * qd + r;
+          const bool masked = q >= S || own >= S || (CAUSAL && own > q);
+          pr[r] = masked ? 0.f : __expf(s2[r] * kScale - lse_s[q]);
+          ds[r] = pr[r] * (dp2[r] - dl_s[q]) * kScale;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int q = 16 * qt + 4 * qd + r;
+#pragma unroll
+          for (int dt = 0; dt < 4; ++dt) {
+            dv[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(dOs[tile_off(q, 16 * dt + l15)], pr[r], dv[dt], 0, 0, 0);
+            dk[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(Qs[tile_off(q, 16 * dt + l15)], ds[r], dk[dt], 0, 0, 0);
+          }
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dSs[tile_off(16 * qt + 4 * qd + r, own)] = ds[r];   // zeros where nothing was computed
+    }
+    if (own < S) {
+      const size_t o = ((size_t)b * S + own) * ldd + h * HD + 4 * qd;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        *reinterpret_cast<f32x4*>(dk_out + o + 16 * dt) = dk[dt];
+        *reinterpret_cast<f32x4*>(dv_out + o + 16 * dt) = dv[dt];
+      }
+    }
+  }
+  __syncthreads();                                   // Q tile dead, dS tile complete
+  stage_tile(Qs, kbase, 0, S, (size_t)a.ldkv);       // K over Q
+  __syncthreads();
+  // ---- phase B: own queries -> dQ^T = K^T dS^T
+  {
+    const float* Ks = Qs;
+    f32x4 dq[4];
+    zero4(dq);
+    const int n1 = CAUSAL ? min(kts, wave + 1) : kts;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+      if (kt < n1) {
+        // dS[own query][keys 16kt + 4qd .. +3]: one 16-byte run of this lane's row of the dS tile
+        const f32x4 dst = *reinterpret_cast<const f32x4*>(dSs + own * HD + (((4 * kt + qd) ^ (own & 15)) << 2));
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = 16 * kt + 4 * qd + r;
+#pragma unroll
+          for (int dt = 0; dt < 4; ++dt)
+            dq[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(Ks[tile_off(key, 16 * dt + l15)], dst[r], dq[dt], 0, 0, 0);
+        }
+      }
+    if (own < S) {
+      float* o = dq_out + ((size_t)b * S + own) * ldd + h * HD + 4 * qd;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) *reinterpret_cast<f32x4*>(o + 16 * dt) = dq[dt];
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------- backward, streamed
 // Long self-attention (Sq == Sk > 80): the two-kernel split of the tiled path (dQ by query blocks; dK, dV by key
 // blocks; no atomics) with the register discipline of attn_fwd_stream_kernel — every score / dP block is formed on
@@ -1137,6 +1274,12 @@ int launch_bwd(const AttnArgs& a, const float* out, const float* dout, const flo
     else
       hipLaunchKernelGGL((attn_bwd_rows_kernel<5, false>), dim3(B * a.H), dim3(320), 0, st, a, out, dout, lse, dq, dk, dv, lddq);
     DCLIP_CHECK_LAUNCH("attention_bwd.rows");
+    return DCLIP_OK;
+  }
+  if (a.Sq == a.Sk && a.Sq <= TS && lddq == lddkv && !getenv("DCLIP_ATTN_FUSED")) {   // one tile, 48 KiB LDS, P / dS in registers
+    if (causal) hipLaunchKernelGGL((attn_bwd_lean_kernel<true>), dim3(B * a.H), block, 0, st, a, out, dout, lse, dq, dk, dv, lddq);
+    else hipLaunchKernelGGL((attn_bwd_lean_kernel<false>), dim3(B * a.H), block, 0, st, a, out, dout, lse, dq, dk, dv, lddq);
+    DCLIP_CHECK_LAUNCH("attention_bwd.lean");
     return DCLIP_OK;
   }
   if (a.Sq == a.Sk && a.Sq <= TS && lddq == lddkv) {  // one-tile self-attention: fused dQ/dK/dV

@@ -45,8 +45,10 @@ for name, B, S, H, causal in [("vision B/32", 256, 50, 12, False), ("text", 256,
         a = t(lambda: ops.attention_bwd(qkv, o, do, l, B, S, H, causal))
         g1 = ops.attention_bwd(qkv, o, do, l, B, S, H, causal)
         os.environ["DCLIP_ATTN_TILED"] = "1"
+        os.environ["DCLIP_ATTN_FUSED"] = "1"
         b = t(lambda: ops.attention_bwd(qkv, o, do, l, B, S, H, causal))
         g2 = ops.attention_bwd(qkv, o, do, l, B, S, H, causal)
+        os.environ.pop("DCLIP_ATTN_FUSED", None)
         err = float((g1 - g2).abs().max() / g2.abs().max())
         mb = (8 * B * S * H * 64 * 4) / 1e6
         print(f"{name}: rows {a:.1f} us ({mb / a / 1e3:.2f} TB/s) | previous {b:.1f} us | max rel diff {err:.2e}", flush=True)
