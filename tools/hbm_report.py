@@ -16,10 +16,10 @@ KERNELS = {
     "ln_bwd_kernel<3>": ("LayerNorm bwd + residual-gradient add (dy, x, dres read; dx written, 16 B/elem)", 4 * rows_v * D * F),
     "attn_fwd_rows_kernel<4, false>": ("vision attention fwd (q,k,v read once, out written)", 4 * rows_v * D * F),
     "attn_fwd_rows_kernel<5, true>": ("text causal attention fwd", 4 * rows_t * Dt * F),
-    "attn_bwd_fused_kernel<false>": ("vision attention bwd (q,k,v,o,do read; dq,dk,dv written)", 8 * rows_v * D * F),
+    "attn_bwd_lean_kernel<false>": ("vision attention bwd (q,k,v,o,do read; dq,dk,dv written)", 8 * rows_v * D * F),
     "mt_adamw_kernel": ("multi-tensor AdamW (p,g,m,v read; p,m,v written, 28 B/param)", 28 * trainable),
     "mt_sumsq_kernel": ("global grad-norm partial sums (g read)", 4 * trainable),
-    "im2col_kernel": ("patch gather (pixels read, columns written)", 2 * B * 3 * 224 * 224 * F),
+    "im2col_vec_kernel<false>": ("patch gather (pixels read, columns written)", 2 * B * 3 * 224 * 224 * F),
 }
 PEAK = 8000.0  # GB/s, MI355X HBM3E (MI355X_MICROARCH.md)
 rep = []
