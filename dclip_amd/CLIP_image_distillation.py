@@ -195,17 +195,28 @@ class CLIPImageDistillation(LightningLikeModule):
         return [optimizer], [scheduler]
 
     # ------------------------------------------------------------------ loaders (:685-693)
-    def _dataset(self, json_file, cache_filename):
+    def _dataset(self, json_file, cache_filename, decode_only=False):
         from .data import MultiModalDataset
         return MultiModalDataset(json_file, self.preprocess, cache_dir=getattr(self.hparams, "cache_dir", "./cache"),
-                                 cache_filename=cache_filename, detector=getattr(self, "detector", None))
+                                 cache_filename=cache_filename, detector=getattr(self, "detector", None),
+                                 decode_only=decode_only)
 
     def train_dataloader(self):
-        """N3: the reference batches the TRAINING set with eval_batch_size (:687); kept."""
+        """N3: the reference batches the TRAINING set with eval_batch_size (:687); kept.  Defaults are the reference's
+        (`num_workers=0`, host preprocessing).  `hparams.gpu_preprocess=True` makes the host only DECODE (in
+        `hparams.num_workers` worker processes) and runs resize / normalise / region crops on the GPU: at ~3900 img/s
+        per GPU the step outruns a single-process PIL pipeline by an order of magnitude."""
         from torch.utils.data import DataLoader
-        from .data import MultiModalDataset
-        ds = self._dataset(self.hparams.train_file, getattr(self.hparams, "train_cache_filename", "train_precache.pkl"))
-        return DataLoader(ds, batch_size=self.hparams.eval_batch_size, num_workers=0, pin_memory=True, shuffle=True,
+        from .data import GpuBatches, MultiModalDataset, identity_collate
+        cache = getattr(self.hparams, "train_cache_filename", "train_precache.pkl")
+        workers = int(getattr(self.hparams, "num_workers", 0))
+        if getattr(self.hparams, "gpu_preprocess", False):
+            ds = self._dataset(self.hparams.train_file, cache, decode_only=True)
+            loader = DataLoader(ds, batch_size=self.hparams.eval_batch_size, num_workers=workers, shuffle=True,
+                                collate_fn=identity_collate, persistent_workers=workers > 0)
+            return GpuBatches(loader, self.device, self.student.config.vision.image_size)
+        ds = self._dataset(self.hparams.train_file, cache)
+        return DataLoader(ds, batch_size=self.hparams.eval_batch_size, num_workers=workers, pin_memory=True, shuffle=True,
                           collate_fn=MultiModalDataset.custom_collate_fn)
 
     def val_dataloader(self):

@@ -232,6 +232,28 @@ class GpuCollate:
                 "weighted_boxes": list(boxes), "images_u8": images_u8, "dims": dims_d}
 
 
+def identity_collate(batch):
+    """For DataLoader workers of a decode_only dataset: hand the list of samples through unchanged (workers must
+    not touch the GPU; `GpuBatches` collates in the main process)."""
+    return batch
+
+
+class GpuBatches:
+    """Iterates a DataLoader of decoded samples (decode_only dataset + identity_collate, any number of worker
+    processes doing the JPEG decoding) and turns every list into a device batch with `GpuCollate` in the main
+    process: the host only decodes, resize / normalise / crops run on the GPU."""
+
+    def __init__(self, loader, device, size: int = 224):
+        self.loader, self.collate = loader, GpuCollate(device, size)
+
+    def __len__(self):
+        return len(self.loader)
+
+    def __iter__(self):
+        for samples in self.loader:
+            yield self.collate(samples)
+
+
 # ----------------------------------------------------------------------------------------------- the dataset
 
 class MultiModalDataset(torch.utils.data.Dataset):

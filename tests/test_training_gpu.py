@@ -216,3 +216,13 @@ def test_reference_batch_format_end_to_end(tmp_path):
     before = m.student.visual_projection.weight.detach().clone()
     Trainer(max_epochs=1, gradient_clip_val=0.5, accumulate_grad_batches=1).fit(m)
     assert not torch.equal(before, m.student.visual_projection.weight.detach())
+    # decode in worker processes, everything else on the GPU
+    m.hparams.gpu_preprocess, m.hparams.num_workers = True, 2
+    gl = m.train_dataloader()
+    assert len(gl) == 2
+    seen = 0
+    for gbatch in gl:
+        assert gbatch["pixel_values"].is_cuda and gbatch["pixel_values"].shape[1:] == (3, 64, 64)
+        assert bool(torch.isfinite(m.training_step(gbatch)))
+        seen += gbatch["pixel_values"].shape[0]
+    assert seen == 8
