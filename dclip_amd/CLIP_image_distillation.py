@@ -113,11 +113,12 @@ class CLIPImageDistillation(LightningLikeModule):
 
     def _step(self, batch, log_name: str, bs_field: str):
         dev = self.device
+        ran_teacher = True
         if isinstance(batch, dict) and "captions" in batch:
             # data.GpuCollate: decoded images already on the device, student preprocessing done there
             images = batch["pixel_values"].to(dev)
             host_tokens = self._tokenize(batch["captions"])
-            tokens = host_tokens.to(dev, non_blocking=True)
+            tokens = host_tokens.to(dev)
             with torch.no_grad():
                 teacher_image = self.teacher.compute_global_embedding_batch(
                     batch["image_paths"], host_tokens, batch["weighted_boxes"], batch.get("images_u8"),
@@ -129,15 +130,16 @@ class CLIPImageDistillation(LightningLikeModule):
             with torch.no_grad():
                 if "teacher_image_emb" in batch:
                     teacher_image = batch["teacher_image_emb"].to(dev).float()
+                    ran_teacher = False
                 else:
                     teacher_image = self.teacher.compute_global_embedding_tensors(
                         batch["regions"].to(dev), tokens, batch.get("region_counts")).float()
                 teacher_text = batch["teacher_text_emb"].to(dev).float() if "teacher_text_emb" in batch else None
         else:
             images, captions, image_paths, weighted_boxes_batch = batch
-            images = images.to(dev, non_blocking=True)        # pinned by the DataLoader (pin_memory=True, :687)
+            images = images.to(dev, non_blocking=images.is_pinned())   # pinned by the DataLoader (pin_memory=True, :687)
             host_tokens = self._tokenize(captions)
-            tokens = host_tokens.to(dev, non_blocking=True)
+            tokens = host_tokens.to(dev)
             with torch.no_grad():
                 # the teacher gets the HOST ids: it sizes its token padding from them without a stream sync
                 teacher_image = self.teacher.compute_global_embedding_batch(
@@ -145,7 +147,15 @@ class CLIPImageDistillation(LightningLikeModule):
             teacher_text = None
         student_image = self.student.get_image_features(pixel_values=images).float()
         loss_image = self.cosine_distillation_loss(student_image, teacher_image)
-        student_text = self.student.get_text_features(input_ids=tokens).float()
+        shared_sentence = None
+        if ran_teacher and self.teacher.shares_text_tower_with(self.student) \
+                and getattr(self.teacher.text_tokenizer, "precision", "fp32") == "fp32":
+            # The meta-teacher has just pushed these captions through the SAME frozen text tower to get its token
+            # embeddings; the sentence embedding is row first-EOS of that pass.  One text forward serves the teacher's
+            # tokens, the teacher's sentence target and the (frozen) student text features.
+            shared_sentence = self.teacher.last_sentence_embedding
+        student_text = (shared_sentence if shared_sentence is not None
+                        else self.student.get_text_features(input_ids=tokens)).float()
         if teacher_text is None:
             with torch.no_grad():
                 if self.teacher.shares_text_tower_with(self.student):

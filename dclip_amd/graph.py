@@ -53,7 +53,10 @@ class GraphedStep:
                 if tuple(v.shape) != tuple(dst.shape) or v.dtype != dst.dtype:
                     raise ValueError(f"GraphedStep: batch[{k!r}] is {tuple(v.shape)}/{v.dtype}, captured "
                                      f"{tuple(dst.shape)}/{dst.dtype} (a HIP graph replays fixed shapes)")
-                dst.copy_(v, non_blocking=True)
+                # pageable host memory: a non-blocking copy is staged by the runtime and is NOT ordered with the graph
+                # launch that follows (seen as a replay on stale inputs, 2e-4 drift of a trainer); only device or
+                # pinned sources may go asynchronously
+                dst.copy_(v, non_blocking=bool(v.is_cuda or v.is_pinned()))
 
     def step(self, batch: Dict[str, torch.Tensor] = None) -> torch.Tensor:
         """Forward + backward on `batch` (None: the data already in the captured buffers).  Returns the loss tensor

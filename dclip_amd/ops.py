@@ -35,18 +35,29 @@ def _ptr(t: Optional[torch.Tensor]):
 
 
 class _Workspace:
-    """Grow-only scratch buffer per device (the library never allocates)."""
+    """Grow-only scratch buffer per device (the library never allocates).  ONE buffer per device, whatever the stream:
+    every launch sequence of this package runs on one stream at a time (a side stream only inside GraphedStep's
+    warm-up, ordered by stream waits), and a buffer keyed by stream would be (re)allocated INSIDE a HIP-graph capture
+    — from the graph's private pool, cached here beyond the graph's life and handed to the next capture on the same
+    stream handle (seen as a 2e-4 drift of a replayed trainer after graph -> eager -> graph).  Outgrown buffers are
+    kept alive (`retired`): a captured graph may still hold their address."""
 
     def __init__(self):
         self.buf = {}
+        self.retired = []
 
     def get(self, nbytes: int, device) -> Optional[torch.Tensor]:
         if nbytes == 0:
             return None
-        key = (device.index, torch.cuda.current_stream().cuda_stream)
+        key = device.index
         b = self.buf.get(key)
         if b is None or b.numel() < nbytes:
-            b = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("workspace growth inside a HIP-graph capture: run the step eagerly once before "
+                                   "capturing (GraphedStep does)")
+            if b is not None:
+                self.retired.append(b)
+            b = torch.empty(max(nbytes, 2 * (b.numel() if b is not None else 0), 1 << 20), dtype=torch.uint8, device=device)
             self.buf[key] = b
         return b
 

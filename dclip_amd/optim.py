@@ -53,14 +53,26 @@ class FusedAdamW(torch.optim.Optimizer):
         if not recs:
             return None
         blob = b"".join(recs)
-        host = self._table.get(gi)
-        if host is None or host[0].numel() < len(blob):
-            host = (torch.empty(len(blob), dtype=torch.uint8).pin_memory(),
-                    torch.empty(len(blob), dtype=torch.uint8, device=keep[0].device))
-            self._table[gi] = host
-        host[0][:len(blob)].copy_(torch.frombuffer(bytearray(blob), dtype=torch.uint8))
-        host[1][:len(blob)].copy_(host[0][:len(blob)], non_blocking=True)
-        return host[1], len(recs), c0, keep
+        # The upload is asynchronous (pinned -> device on the compute stream) and the host runs ahead of the GPU, so
+        # the pinned staging buffer of step n must not be rewritten for step n+1 before its copy has executed (the
+        # kernel of step n would read step n+1's bias-correction counters): a small ring of staging buffers, each
+        # guarded by the event recorded behind its last copy.
+        ring = self._table.get(gi)
+        if ring is None or ring["dev"].numel() < len(blob):
+            ring = {"dev": torch.empty(len(blob), dtype=torch.uint8, device=keep[0].device),
+                    "host": [torch.empty(len(blob), dtype=torch.uint8).pin_memory() for _ in range(4)],
+                    "done": [None] * 4, "next": 0}
+            self._table[gi] = ring
+        i = ring["next"]
+        ring["next"] = (i + 1) % 4
+        if ring["done"][i] is not None:
+            ring["done"][i].synchronize()            # four steps ago: already finished unless the host is far ahead
+        ring["host"][i][:len(blob)].copy_(torch.frombuffer(bytearray(blob), dtype=torch.uint8))
+        ring["dev"][:len(blob)].copy_(ring["host"][i][:len(blob)], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        ring["done"][i] = ev
+        return ring["dev"], len(recs), c0, keep
 
     @torch.no_grad()
     def step(self, closure=None):

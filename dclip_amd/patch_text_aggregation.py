@@ -340,6 +340,7 @@ class PatchTextAggregation(nn.Module):
         self.cross_modal_attention = CrossModalAttention(embed_dim, num_heads)
         self.knn_cache = {}
         self.use_knn_projection = False
+        self.last_sentence_embedding = None
         self.advanced_tokenizer = None
         self.full_resolution = False
 
@@ -379,6 +380,7 @@ class PatchTextAggregation(nn.Module):
                 rmax = max(int(region_counts.max()), 1)        # an image without boxes keeps ONE zero row (:489-491)
                 emb = ops.mask_rows(emb.contiguous(), counts)[:, :rmax].contiguous()
             sent, tokens, eos = self.text_tokenizer.token_level_ids(input_ids)
+            self.last_sentence_embedding = sent       # text_projection(final_LN(h)[first EOS]) of THIS call's captions
             if max_tokens is None:
                 max_tokens = max(int(eos.max()) - 1, 1)       # host sync; pass max_tokens to avoid it
             text = ops.pack_tokens(tokens.contiguous(), sent, eos, max_tokens)

@@ -354,3 +354,31 @@ def test_teacher_path_based_signature(dev, tmp_path):
     assert relerr(got, want.cpu()) < 1e-6
     embs = teacher.patch_tokenizer.encode_weighted_bounding_boxes(Image.open(paths[2]).convert("RGB"), boxes[2])
     assert len(embs) == 2 and embs[0][0].shape == (cfg.projection_dim,) and embs[0][1] == 0.9
+
+
+def test_one_text_forward_serves_teacher_and_student(dev):
+    """Meta-teacher inside the step on the student's own frozen text tower: the sentence embedding is taken from the
+    teacher's token-level pass; the losses equal those of the path with a separate student text forward."""
+    cfg = dcfg.tiny()
+    B = 5
+    batch = {"pixel_values": synth.synth_pixel_values(B, cfg.vision, seed=1),
+             "input_ids": synth.synth_input_ids(B, cfg.text, seed=2, ragged=True),
+             "regions": synth.synth_regions(B, 3, cfg.vision, seed=3), "region_counts": torch.tensor([3, 1, 0, 2, 3])}
+    res = {}
+    for shared in (True, False):
+        mod = _distill_module(cfg, synth.synth_clip_state_dict(cfg, seed=7, gain=4.0), dev, "north_star")
+        assert mod.teacher.shares_text_tower_with(mod.student)
+        calls = []
+        orig = mod.student.get_text_features
+        mod.student.get_text_features = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+        if not shared:
+            mod.teacher.shares_text_tower_with = lambda s: False
+        loss = mod.training_step(batch)
+        loss.backward()
+        res[shared] = (float(loss), {k: float(v) for k, v in mod.last_losses.items()}, len(calls),
+                       mod.student.visual_projection.weight.grad.clone())
+    assert res[True][2] == 0 and res[False][2] == 1                  # no separate student text forward when shared
+    assert abs(res[True][0] - res[False][0]) < 1e-5 * abs(res[False][0])
+    for k in res[True][1]:
+        assert abs(res[True][1][k] - res[False][1][k]) < 1e-5
+    assert relerr(res[True][3], res[False][3]) < 1e-4
