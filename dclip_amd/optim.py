@@ -104,4 +104,9 @@ class FusedAdamW(torch.optim.Optimizer):
             _lib.check(lib.dclip_mt_adamw_f32(tab.data_ptr(), nt, nchunks, float(group["lr"]), float(b1), float(b2),
                                               float(group["eps"]), float(group["weight_decay"]),
                                               None if coef is None else coef.data_ptr(), stream), "mt_adamw")
+        # the kernel wrote the parameters through raw pointers: tell autograd / every cache keyed on tensor versions
+        # (HipCLIPModel._bf16_cache) that they changed
+        touched = [p for group, _t in tables for p in group["params"] if p.grad is not None]
+        if touched:
+            torch._C._increment_version(touched)
         return loss

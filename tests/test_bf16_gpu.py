@@ -168,3 +168,24 @@ def test_im2col_bf16_equals_im2col_then_round(B, S, p):
     assert got.dtype == torch.bfloat16 and torch.equal(got[:, :want.shape[1]], want)
     ref = pix.cpu().unfold(2, p, p).unfold(3, p, p).permute(0, 2, 3, 1, 4, 5).reshape(B * (S // p) ** 2, 3 * p * p)
     assert torch.equal(ops.im2col(pix, p).cpu(), ref)                    # the vectorised fp32 path
+
+
+def test_bf16_weight_cache_follows_the_fused_optimizer():
+    """FusedAdamW updates parameters through raw pointers; the bf16 weight copies (keyed on tensor versions) must be
+    rebuilt afterwards."""
+    from dclip_amd.clip_model import from_hf_state_dict
+    from dclip_amd.optim import FusedAdamW
+    dev = torch.device("cuda:0")
+    cfg = dcfg.tiny()
+    m = from_hf_state_dict(cfg, synth.synth_clip_state_dict(cfg, seed=0, gain=3.0), device=dev)
+    pix = synth.synth_pixel_values(3, cfg.vision, seed=2).to(dev)
+    with torch.no_grad():
+        before = m.get_image_features(pixel_values=pix, precision="bf16")
+    params = [p for p in m.vision_model.parameters()] + [m.visual_projection.weight]
+    m.get_image_features(pixel_values=pix).square().sum().backward()
+    FusedAdamW(params, lr=1e-2).step()
+    with torch.no_grad():
+        after16 = m.get_image_features(pixel_values=pix, precision="bf16")
+        after32 = m.get_image_features(pixel_values=pix)
+    assert float((after16 - before).abs().max()) > 1e-3                      # the update is visible on the bf16 path
+    assert float((after16 - after32).abs().max() / after32.abs().max()) < 3e-2
