@@ -83,7 +83,9 @@ def _embeddings(teacher: PatchTextAggregation, batch):
     else:
         _, captions, image_paths, weighted_boxes_batch = batch
         img = teacher.compute_global_embedding_batch(image_paths, captions, weighted_boxes_batch)
-        txt = torch.stack([teacher.text_tokenizer.aggregate_text(c) for c in captions])
+        # the reference calls aggregate_text once per caption (:346): the sentence embeddings of these very captions
+        # are row first-EOS of the token-level pass the call above has just made — no further text forward
+        txt = teacher.last_sentence_embedding
     return img, txt
 
 

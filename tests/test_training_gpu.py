@@ -226,3 +226,45 @@ def test_reference_batch_format_end_to_end(tmp_path):
         assert bool(torch.isfinite(m.training_step(gbatch)))
         seen += gbatch["pixel_values"].shape[0]
     assert seen == 8
+
+
+def test_teacher_trainer_on_reference_batches(tmp_path):
+    """train_contrastive_teacher.main over (images, captions, paths, boxes) tuples built from a JSON file with image
+    files: the path-based teacher + the shared text pass; checkpoints written, loss finite."""
+    import json
+    from PIL import Image
+    from dclip_amd import train_contrastive_teacher as T
+    from dclip_amd.patch_text_aggregation import PatchTextAggregation
+    dev = torch.device("cuda:0")
+    cfg = dcfg.tiny(image_size=64, patch_size=16)
+    from dclip_amd.clip_model import from_hf_state_dict
+    clip = from_hf_state_dict(cfg, synth.synth_clip_state_dict(cfg, seed=7, gain=4.0), device=dev)
+    Tm = cfg.text.max_position_embeddings
+
+    class Tok:
+        def __call__(self, text, **kw):
+            caps = [text] if isinstance(text, str) else list(text)
+            rows = [[cfg.text.bos_token_id] + [1 + (sum(map(ord, w)) % (cfg.text.bos_token_id - 2)) for w in c.split()][:Tm - 2]
+                    + [cfg.text.eos_token_id] for c in caps]
+            L = max(len(r) for r in rows)
+            ids = torch.full((len(rows), L), cfg.text.eos_token_id, dtype=torch.int64)
+            for b, r in enumerate(rows):
+                ids[b, :len(r)] = torch.tensor(r)
+            return type("Enc", (), {"input_ids": ids})()
+
+    recs = []
+    for i in range(6):
+        p = tmp_path / f"t{i}.png"
+        Image.fromarray(synth.synth_photo(72 + 4 * i, 96, seed=60 + i)).save(p)
+        recs.append({"image_path": str(p), "captions": [f"a picture of item {i} on a table"],
+                     "boxes": [[[2 * i, 3, 50 + i, 40 + i], 0.8]] * (i % 3)})
+    (tmp_path / "train.json").write_text(json.dumps(recs))
+    teacher = PatchTextAggregation(embed_dim=cfg.projection_dim, num_heads=1, clip_model=clip, tokenizer=Tok()).to(dev)
+    args = argparse.Namespace(train_file=str(tmp_path / "train.json"), val_file=str(tmp_path / "train.json"), batch_size=3,
+                              gradient_accumulation=8, learning_rate=1e-3, epochs=2,
+                              output_path=str(tmp_path / "out" / "teacher.pth"))
+    res = T.main(args, teacher=teacher)
+    assert all(torch.isfinite(torch.tensor(h)).all() for h in res["history"])
+    assert os.path.exists(args.output_path)
+    sd = torch.load(args.output_path, weights_only=True)
+    assert len(sd) == 12
