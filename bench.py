@@ -23,6 +23,9 @@ import time
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
+# the host driver only supports dmabuf IPC: RCCL / device-tensor sharing across ranks needs this (already exported on the
+# pool's boxes; set here as well so a bare launch behaves the same)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
