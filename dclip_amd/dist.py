@@ -62,8 +62,10 @@ class GradSync:
     (~`bucket_mb`, one ViT-B layer = 28 MB) and the bucket's all-reduce is launched with async_op — RCCL runs it on
     its own stream over xGMI while the compute stream keeps back-propagating the layers below.  `finish()` (after
     `loss.backward()`) reduces whatever the hook never saw (parameters outside the hooked tower), waits for every
-    bucket and writes the reduced values into `param.grad`.  Without the hook installed, `reduce()` = finish()
-    does everything after the backward (still bucketed and asynchronous among buckets)."""
+    bucket and points each `param.grad` at its slice of the reduced bucket (no copy back).  Without the hook
+    installed, `reduce()` = finish() does everything after the backward (still bucketed and asynchronous among
+    buckets).  One backward per `finish()`: with gradient accumulation call it after the LAST micro-batch only and
+    without the overlap hook (the hook sees a micro-batch's gradients, not the accumulated ones)."""
 
     def __init__(self, params: Iterable[torch.nn.Parameter], group, bucket_mb: float = 25.0):
         self.group = group
