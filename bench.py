@@ -98,17 +98,25 @@ class GemmTimer:
         return flops, ms, len(self.records)
 
 
-def cpu_baseline(seconds: float = 12.0):
+def cpu_baseline(seconds: float = 12.0, regime: str = "north_star"):
     """The reference's step arithmetic restated on the CPU (oracle/dclip_oracle.py, pinned to the reference's own
-    outputs by tests/golden): BASELINE config c1 — ViT-B/32 + text tower, bs=8, forward + backward — timed on the
-    host cores for a bounded sample."""
+    outputs by tests/golden), ViT-B/32 + text tower, forward + backward, timed on the host cores for a bounded sample.
+      regime "north_star": the SAME regime as the GPU number — vision tower trainable, text tower frozen with one
+                           forward shared by student and teacher, teacher image embedding given; bs 32;
+      regime "as_written": BASELINE config c1 exactly — bs 8, every tower trainable as the reference's step leaves them."""
     from oracle import dclip_oracle as O
     cores = max(1, min(os.cpu_count() or 1, len(os.sched_getaffinity(0)), 32))
     torch.set_num_threads(cores)
     cfg = dcfg.vit_b32()
     sd = synth.synth_clip_state_dict(cfg, seed=0)
-    p = {k: v.clone().requires_grad_(v.is_floating_point() and v.dim() > 0) for k, v in sd.items()}
-    B = 8
+    if regime == "north_star":
+        B = 32
+        p = {k: v.clone().requires_grad_(v.is_floating_point() and v.dim() > 0
+                                         and (k.startswith("vision_model.") or k == "visual_projection.weight"))
+             for k, v in sd.items()}
+    else:
+        B = 8
+        p = {k: v.clone().requires_grad_(v.is_floating_point() and v.dim() > 0) for k, v in sd.items()}
     pix = synth.synth_pixel_values(B, cfg.vision, seed=0)
     ids = synth.synth_input_ids(B, cfg.text, seed=3)
     t_img = synth.synth_embeddings(B, cfg.projection_dim, seed=1)
@@ -125,10 +133,36 @@ def cpu_baseline(seconds: float = 12.0):
         one()
         n += 1
     dt = time.perf_counter() - t0
+    what = ("north_star regime as in `value`: vision trainable, text frozen + shared forward, teacher image embedding given"
+            if regime == "north_star" else
+            "BASELINE config c1: all towers trainable as in the reference's as-written step")
     return {"value": round(B * n / dt, 3), "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": f"config c1: ViT-B/32 + text tower, bs={B}, fwd+bwd, {n} steps in {dt:.1f} s "
-                      f"(oracle/dclip_oracle.py, torch {torch.__version__} CPU, all towers trainable as in the "
-                      f"reference's as-written step)"}
+            "sample": f"ViT-B/32 + text tower, bs={B}, fwd+bwd, {n} steps in {dt:.1f} s; {what} "
+                      f"(oracle/dclip_oracle.py, torch {torch.__version__} CPU)"}
+
+
+def self_launch(n: int) -> int:
+    """Run `python -m torch.distributed.run --nnodes=1 --nproc-per-node n bench.py <same args>` as a child process,
+    relay rank 0's JSON line (the only thing the ranks print on stdout) and return the child's exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+    for ln in proc.stdout.splitlines():
+        if ln not in lines:
+            print(ln, file=sys.stderr)
+    if proc.returncode == 0 and lines:
+        print(lines[-1], flush=True)
+        return 0
+    print(f"bench.py: the {n}-rank launch failed (exit code {proc.returncode})", file=sys.stderr)
+    return proc.returncode or 1
 
 
 def main():
@@ -141,26 +175,40 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-optimizer", action="store_true", help="time forward+backward only")
     ap.add_argument("--no-gemm-events", action="store_true", help="do not bracket GEMM launches with HIP events")
+    ap.add_argument("--no-extra-legs", action="store_true",
+                    help="skip the untimed-by-the-contract extra measurements after the timed region (forward+backward "
+                         "without the optimizer; HIP-graph replay)")
     ap.add_argument("--graph", action="store_true",
                     help="replay forward+backward from a captured HIP graph (dclip_amd/graph.py; N=1 only).  Per-launch "
                          "GEMM events do not exist inside a graph: `roofline` is then taken from an eager pass of the "
                          "same step before the timed region")
-    ap.add_argument("--workload", default="c2", choices=["c2", "c3"],
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c5"],
                     help="c2 (default, the benched config): teacher image embedding given.  c3: the meta-teacher runs "
-                         "inside the step on --regions crops per image (separate frozen teacher CLIP of --teacher-model)")
+                         "inside the step on --regions crops per image (separate frozen teacher CLIP of --teacher-model). "
+                         "c5: c3 with a ViT-L/14 teacher (768-wide, bridged to the 512-wide ViT-B/32 student by the "
+                         "declared frozen projection) and bf16 teacher towers unless --tower-precision says otherwise")
     ap.add_argument("--regions", type=int, default=8)
     ap.add_argument("--teacher-model", default=None, choices=list(dcfg.NAMED))
-    ap.add_argument("--tower-precision", default="fp32", choices=["fp32", "bf16"],
-                    help="c3 only: GEMM input precision of the FROZEN teacher towers (student is always fp32)")
+    ap.add_argument("--tower-precision", default=None, choices=["fp32", "bf16"],
+                    help="c3 / c5: GEMM input precision of the FROZEN teacher towers (student is always fp32); default "
+                         "fp32 for c3, bf16 for c5")
     args = ap.parse_args()
+    if args.workload == "c5":
+        args.teacher_model = args.teacher_model or "ViT-L/14"
+        args.tower_precision = args.tower_precision or "bf16"
+    args.tower_precision = args.tower_precision or "fp32"
+    meta = args.workload in ("c3", "c5")
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # bare `python bench.py --gpus N`: start the N ranks ourselves.  Nothing in this process has touched the GPU
+        # yet (no HIP call, no torch.cuda.is_available()), and the ranks are CHILD processes (never an exec).
+        raise SystemExit(self_launch(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit(f"--gpus {args.gpus} needs one process per GPU: launch with "
-                             f"python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py ...")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
+                         f"(python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...)")
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback)"
     ndev = torch.cuda.device_count()
     backend = os.environ.get("DCLIP_DIST_BACKEND", "nccl")     # "gloo" lets N ranks share one GPU for a rehearsal
@@ -179,15 +227,14 @@ def main():
     cfg = dcfg.NAMED[args.model]()
     student = from_hf_state_dict(cfg, synth.synth_clip_state_dict(cfg, seed=0), device=dev)   # same init on all ranks
     tcfg = None
-    if args.workload == "c3":
+    if meta:
         tcfg = dcfg.NAMED[args.teacher_model or args.model]()
-        if tcfg.projection_dim != cfg.projection_dim:
-            raise SystemExit("teacher and student must share the embedding width")
         teacher_clip = from_hf_state_dict(tcfg, synth.synth_clip_state_dict(tcfg, seed=7), device=dev)
         for p_ in teacher_clip.parameters():
             p_.requires_grad = False
-        teacher = PatchTextAggregation(embed_dim=cfg.projection_dim, num_heads=cfg.projection_dim // 64,
-                                       clip_model=teacher_clip, tower_precision=args.tower_precision).to(dev)
+        E = tcfg.projection_dim               # a wider teacher is bridged to the student inside the module (c5)
+        teacher = PatchTextAggregation(embed_dim=E, num_heads=E // 64, clip_model=teacher_clip,
+                                       tower_precision=args.tower_precision).to(dev)
     else:
         teacher = PatchTextAggregation(embed_dim=cfg.projection_dim, num_heads=cfg.projection_dim // 64,
                                        clip_model=student).to(dev)
@@ -207,7 +254,7 @@ def main():
         "pixel_values": synth.synth_pixel_values(B, cfg.vision, seed=rank).to(dev),
         "input_ids": synth.synth_input_ids(B, cfg.text, seed=100 + rank).to(dev),
     }
-    if args.workload == "c3":
+    if meta:
         batch["regions"] = synth.synth_regions(B, args.regions, tcfg.vision, seed=2000 + rank).to(dev)
     else:
         batch["teacher_image_emb"] = synth.synth_embeddings(B, cfg.projection_dim, seed=1000 + rank).to(dev)
@@ -216,6 +263,11 @@ def main():
     if not args.no_gemm_events:
         timer.install()
 
+    def eager_fwd_bwd():
+        for p_ in trainable:
+            p_.grad = None
+        module.training_step(batch).backward()
+
     graphed = None
     if args.graph:
         if world > 1:
@@ -223,9 +275,7 @@ def main():
         from dclip_amd.graph import GraphedStep
         timer.enabled = True                     # eager pass: per-launch GEMM events for the roofline figure
         for _ in range(2):
-            for p_ in trainable:
-                p_.grad = None
-            module.training_step(batch).backward()
+            eager_fwd_bwd()
         torch.cuda.synchronize()
         timer.enabled = False
         eager_gemm = timer.summary()
@@ -234,17 +284,17 @@ def main():
             p_.grad = None
         graphed = GraphedStep(module, batch)
 
-    def step():
+    def step(with_opt=True):
         if graphed is not None:
             loss = graphed.step()                # inputs already sit in the captured buffers
-            if opt is not None:
+            if opt is not None and with_opt:
                 opt.step()                       # gradients stay allocated in the graph's pool: no zero_grad
             return loss
         loss = module.training_step(batch)      # N > 1: this rank's share of the global loss (dist.py)
         loss.backward()
         if sync is not None:
             sync.finish()
-        if opt is not None:
+        if opt is not None and with_opt:
             opt.step()
             opt.zero_grad(set_to_none=True)
         else:
@@ -252,37 +302,78 @@ def main():
                 p.grad = None
         return loss
 
+    def timed(n, fn):
+        """n calls of fn bracketed by synchronize (+ barrier) on both sides; MAX over ranks, seconds."""
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = None
+        for _ in range(n):
+            out = fn()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t)
+        return el, out
+
     for _ in range(args.warmup):
         step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
+    if sync is not None:
+        sync.reset_stats()
     timer.enabled = graphed is None
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        last = step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    elapsed, last = timed(args.steps, step)            # ---- THE timed region: exactly K steps
     timer.enabled = False
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t)
+    comm = sync.stats() if sync is not None else None
+
+    # ---- extra legs, outside the contract's timed region (SURVEY §8d: "optimizer excluded and reported separately")
+    extra = {}
+    if not args.no_extra_legs and graphed is None:
+        n_x = max(3, min(args.steps, 10))
+        if opt is not None:
+            el, _ = timed(n_x, lambda: step(with_opt=False))
+            extra["fwd_bwd_ms_per_step"] = round(el * 1e3 / n_x, 3)
+            extra["fwd_bwd_images_per_s"] = round(world * B * n_x / el, 2)
+            extra["optimizer_ms_per_step"] = round(elapsed * 1e3 / args.steps - el * 1e3 / n_x, 3)
+        if world == 1:
+            try:
+                from dclip_amd.graph import GraphedStep
+                for p_ in trainable:
+                    p_.grad = None
+                gs = GraphedStep(module, batch)
+
+                def gstep():
+                    loss = gs.step()
+                    if opt is not None:
+                        opt.step()
+                    return loss
+
+                for _ in range(2):
+                    gstep()
+                el, _ = timed(n_x, gstep)
+                extra["graph_ms_per_step"] = round(el * 1e3 / n_x, 3)
+                extra["graph_images_per_s"] = round(B * n_x / el, 2)
+                del gs
+            except Exception as exc:            # a graph variant is informative only; never fail the bench line on it
+                extra["graph_error"] = f"{type(exc).__name__}: {exc}"[:200]
 
     if rank == 0:
         ms_per_step = elapsed * 1e3 / args.steps
         value = world * B * args.steps / elapsed
         step_flops = step_flops_per_image(cfg, T) * B
         teacher_flops = 0.0
-        if args.workload == "c3":      # + R frozen region forwards + the teacher's own text forward + cross-attention
-            E, R = cfg.projection_dim, args.regions
+        if meta:      # + R frozen region forwards + the teacher's own text forward + cross-attention (+ the bridge)
+            E, R = tcfg.projection_dim, args.regions
             teacher_flops = B * (R * (vision_fwd_flops(tcfg.vision) + 2.0 * tcfg.vision.hidden_size * E)
                                  + text_fwd_flops(tcfg.text, T) + 2.0 * T * tcfg.text.hidden_size * E
-                                 + 8.0 * E * E * (T + R) + 8.0 * T * R * E)
+                                 + 8.0 * E * E * (T + R) + 8.0 * T * R * E
+                                 + (4.0 * E * cfg.projection_dim if E != cfg.projection_dim else 0.0))
         gflops, gms, glaunches = timer.summary() if not args.no_gemm_events else (0.0, 0.0, 0)
         if graphed is not None:                  # scale the eager per-step figures to the K timed steps
             gflops, gms, glaunches = eager_gemm[0] * args.steps, eager_gemm[1] * args.steps, eager_gemm[2] * args.steps
@@ -291,10 +382,21 @@ def main():
             for (M_, N_, K_, lay), (n, ms, tf) in sorted(timer.by_shape().items(), key=lambda kv: -kv[1][1]):
                 print(f"gemm M={M_:6d} N={N_:5d} K={K_:6d} layout={lay} launches/step={n / args.steps:5.1f} "
                       f"ms/step={ms / args.steps:7.3f} {tf:6.1f} TF/s", file=sys.stderr)
-        traffic = None
+        traffic, traffic_source = None, None
         pmc = os.path.join(REPO, "profiles", "gemm_traffic.json")
         if os.path.exists(pmc):
             traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            traffic_source = "profiles/gemm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, " \
+                             "committed; NOT re-measured in this run)"
+        if args.workload == "c2":
+            wl = (f"BASELINE config c2: {cfg.name} distill step, bs={B}/GPU, 224x224 + {T}-token synthetic pairs, "
+                  f"contrastive+cosine loss, fp32, vision trainable / text frozen (north_star regime), ")
+        else:
+            wl = (f"BASELINE config {args.workload} (extra, not the benched config): {cfg.name} student fp32 + meta-teacher "
+                  f"in the step ({args.regions} region crops/img through a frozen {tcfg.name} tower with "
+                  f"{args.tower_precision} GEMM inputs, token-level text, cross-modal attention + aggregation"
+                  + (f", {tcfg.projection_dim}->{cfg.projection_dim} teacher bridge" if module.teacher_bridge is not None
+                     else "") + f"), bs={B}/GPU, ")
         line = {
             "metric": "distill-step images/sec at ViT-B/32 bs=256",
             "value": round(value, 2),
@@ -308,14 +410,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": (f"BASELINE config c2: {cfg.name} distill step, bs={B}/GPU, 224x224 + {T}-token "
-                                    f"synthetic pairs, contrastive+cosine loss, fp32, vision trainable / text frozen "
-                                    f"(north_star regime), " if args.workload == "c2" else
-                                    f"BASELINE config c3 (extra, not the benched config): {cfg.name} student fp32 + "
-                                    f"meta-teacher in the step ({args.regions} region crops/img through a frozen "
-                                    f"{tcfg.name} tower with {args.tower_precision} GEMM inputs, token-level text, "
-                                    f"cross-modal attention + aggregation), bs={B}/GPU, ")
-                                   + ("fwd+bwd only" if opt is None else "fwd+bwd + clip-norm 0.5 + AdamW")
+            "config": {"workload": wl + ("fwd+bwd only" if opt is None else "fwd+bwd + clip-norm 0.5 + AdamW")
                                    + (", fwd+bwd replayed from a HIP graph" if graphed is not None else ""),
                        "global_batch": world * B, "parallelism": f"dp{world}",
                        "loss": float(last.detach())},
@@ -323,7 +418,7 @@ def main():
                          "achieved": None if achieved is None else round(achieved, 2),
                          "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": None if achieved is None else round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
-                         "traffic": traffic,
+                         "traffic": traffic, "traffic_source": traffic_source,
                          "launches_per_step": glaunches // max(1, args.steps),
                          "gemm_ms_per_step": round(gms / max(1, args.steps), 3),
                          "gemm_flops_per_step": gflops / max(1, args.steps)},
@@ -337,7 +432,8 @@ def main():
                                   gflops / max(1, args.steps) / (ms_per_step * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
                               "flops_per_image": step_flops_per_image(cfg, T)},
         }
-        if args.workload == "c3":
+        line.update(extra)
+        if meta:
             # mixed-precision floor: student flops at the fp32 matrix peak + frozen-teacher flops at the peak of the
             # precision they were multiplied in (bf16 dense 2500 TF/s, MI355X_MICROARCH.md)
             tpeak = 2500.0 if args.tower_precision == "bf16" else PEAK_F32_MFMA_TFLOPS
@@ -346,8 +442,13 @@ def main():
                                      "frac": round(t_min_ms / ms_per_step, 4),
                                      "student_flops_per_image": step_flops / B, "teacher_flops_per_image": teacher_flops / B,
                                      "teacher_peak_tflops": tpeak}
+        if comm is not None:
+            line["comm"] = dict(comm, backend=backend, ranks=dist.get_world_size(group),
+                                embedding_all_gather_bytes_per_rank=2 * B * cfg.projection_dim * 4)
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(float(os.environ.get("DCLIP_BENCH_CPU_SECONDS", "12")))
+            secs = float(os.environ.get("DCLIP_BENCH_CPU_SECONDS", "12"))
+            line["cpu_baseline"] = cpu_baseline(secs, "north_star")          # same regime as `value`
+            line["cpu_baseline_c1"] = cpu_baseline(secs, "as_written")       # BASELINE config c1 as the reference runs it
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

@@ -34,6 +34,33 @@ def distill_losses(student_image: torch.Tensor, student_text: torch.Tensor, teac
     return {"loss": l_img + l_txt + 1.0 * l_con, "loss_image": l_img, "loss_text": l_txt, "loss_contrastive": l_con}
 
 
+def bridge_weight(student_dim: int, teacher_dim: int, seed: int = 0) -> torch.Tensor:
+    """The frozen teacher→student bridge of BASELINE config c5 (ViT-L/14 teacher, P=768 → ViT-B/32 student, P=512):
+    a seeded Gaussian [student_dim, teacher_dim] matrix, std teacher_dim^-1/2, drawn on the CPU with an explicit
+    generator so every rank / run / the oracle derive the same matrix.
+
+    DECLARED RULE — the reference has none: its `cosine_distillation_loss` would raise on the width mismatch
+    (training/CLIP_image_distillation.py:573; "FIX THIS IF GOING FROM VIT L TO VIT B",
+    training/patch_text_aggregation.py:51).  A random projection keeps the cosine geometry of the teacher space up to
+    Johnson–Lindenstrauss distortion, has no trainable state, and is stored in the student checkpoint under its own
+    key (`teacher_bridge.weight`) so a run can be resumed / evaluated against the same targets."""
+    gen = torch.Generator().manual_seed(1_000_003 + int(seed))
+    return torch.randn((student_dim, teacher_dim), generator=gen, dtype=torch.float32) * float(teacher_dim) ** -0.5
+
+
+class TeacherBridge(torch.nn.Module):
+    """t [B, P_teacher] -> t @ W^T [B, P_student]; W is a frozen buffer (never a Parameter: AdamW must not see it)."""
+
+    def __init__(self, student_dim: int, teacher_dim: int, seed: int = 0):
+        super().__init__()
+        self.register_buffer("weight", bridge_weight(student_dim, teacher_dim, seed))
+
+    @torch.no_grad()
+    def forward(self, t: torch.Tensor) -> torch.Tensor:
+        from . import ops
+        return ops.gemm(t.float().contiguous(), self.weight, ops.LAYOUT_NT)
+
+
 def _as_hip_model(clip_model) -> HipCLIPModel:
     if isinstance(clip_model, HipCLIPModel):
         return clip_model
@@ -53,15 +80,30 @@ class CLIPImageDistillation(LightningLikeModule):
         self.process_group = process_group
         self.temperature = 0.05
         if teacher is None:
+            # The reference's teacher loads its OWN CLIP instances and never updates them
+            # (training/image_tokenizer.py:25, training/text_tokenizer.py:21).  Nothing is fetched by name here, so the
+            # default teacher takes a frozen SNAPSHOT of the student's towers at construction: the distillation target
+            # must not move with the student (the vision tower trains in both freeze modes).
+            import copy
             from .patch_text_aggregation import PatchTextAggregation
             E = self.student.config.projection_dim               # 512 / 8 heads in the reference (:446-452)
-            teacher = PatchTextAggregation(embed_dim=E, num_heads=max(1, E // 64), clip_model=self.student)
+            snapshot = copy.deepcopy(self.student)
+            object.__setattr__(snapshot, "_bf16_w", None)
+            for p in snapshot.parameters():
+                p.requires_grad = False
+            teacher = PatchTextAggregation(embed_dim=E, num_heads=max(1, E // 64), clip_model=snapshot,
+                                           owns_clip=True, text_twin=self.student)
+            teacher.to(next(self.student.parameters()).device)
         self.teacher = teacher
         if contrastive_teacher_path:
             # weights_only: a checkpoint is data, nothing in it is executed (training/CLIP_image_distillation.py:458-462)
             sd = torch.load(contrastive_teacher_path, map_location="cpu", weights_only=True)
             self.teacher.load_state_dict(sd, strict=False)
         self.teacher.eval()
+        # config c5: a teacher wider than the student (L/14 → B/32) is bridged by the declared frozen projection
+        t_dim, s_dim = int(self.teacher.embed_dim), int(self.student.config.projection_dim)
+        self.teacher_bridge = None if t_dim == s_dim else TeacherBridge(
+            s_dim, t_dim, int(getattr(self.hparams, "bridge_seed", 0)))
         self.set_freeze_mode(freeze_mode)
 
     # ------------------------------------------------------------------ freeze rules
@@ -114,6 +156,7 @@ class CLIPImageDistillation(LightningLikeModule):
     def _step(self, batch, log_name: str, bs_field: str):
         dev = self.device
         ran_teacher = True
+        self.teacher.last_sentence_embedding = None
         if isinstance(batch, dict) and "captions" in batch:
             # data.GpuCollate: decoded images already on the device, student preprocessing done there
             images = batch["pixel_values"].to(dev)
@@ -145,6 +188,11 @@ class CLIPImageDistillation(LightningLikeModule):
                 teacher_image = self.teacher.compute_global_embedding_batch(
                     image_paths, host_tokens, weighted_boxes_batch).to(dev).float()
             teacher_text = None
+        if self.teacher_bridge is not None:
+            if teacher_image.shape[1] != self.student.config.projection_dim:      # given targets may be pre-bridged
+                teacher_image = self.teacher_bridge(teacher_image)
+            if teacher_text is not None and teacher_text.shape[1] != self.student.config.projection_dim:
+                teacher_text = self.teacher_bridge(teacher_text)
         student_image = self.student.get_image_features(pixel_values=images).float()
         loss_image = self.cosine_distillation_loss(student_image, teacher_image)
         shared_sentence = None
@@ -161,8 +209,14 @@ class CLIPImageDistillation(LightningLikeModule):
                 if self.teacher.shares_text_tower_with(self.student):
                     # frozen student text tower == teacher text tower: one forward serves both
                     teacher_text = student_text.detach()
+                elif ran_teacher and self.teacher.last_sentence_embedding is not None:
+                    # a separate teacher tower has just encoded these captions for its token embeddings: the sentence
+                    # target (aggregate_text, :605-608) is row first-EOS of that very pass — no second teacher forward
+                    teacher_text = self.teacher.last_sentence_embedding.float()
                 else:
                     teacher_text = self.teacher.text_tokenizer.aggregate_text_ids(tokens).float()
+                if self.teacher_bridge is not None:
+                    teacher_text = self.teacher_bridge(teacher_text)
         loss_text = self.cosine_distillation_loss(student_text, teacher_text)
         contrastive = self.compute_contrastive_loss(student_image, student_text)
         if self.process_group is None:

@@ -76,6 +76,7 @@ SIGNATURES = {
     "dclip_mt_chunk_elems": (I, []),
     "dclip_mt_sumsq_f32": (I, [P, I, I, P, P]),
     "dclip_mt_adamw_f32": (I, [P, I, I, F, F, F, F, F, P, P]),
+    "dclip_mt_adam_f32": (I, [P, I, I, F, F, F, F, F, P, P]),
     "dclip_axpby": (I, [P, P, F, F, Z, P]),
     "dclip_fill": (I, [P, F, Z, P]),
 }

@@ -120,6 +120,9 @@ __global__ void __launch_bounds__(256) mt_sumsq_kernel(const TensorRef* __restri
   if (threadIdx.x == 0) partial[chunk] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
+// COUPLED = false: AdamW (decoupled decay, torch.optim.AdamW);  COUPLED = true: Adam with L2 folded into the gradient
+// (g += wd * p, torch.optim.Adam — the teacher trainer's optimizer, training/train_contrastive_teacher.py:245-248)
+template <bool COUPLED>
 __global__ void __launch_bounds__(256) mt_adamw_kernel(const TensorRef* __restrict__ refs, int ntensors, float lr, float beta1,
                                                        float beta2, float eps, float wd, const float* __restrict__ grad_scale) {
   const int chunk = blockIdx.x;
@@ -129,12 +132,13 @@ __global__ void __launch_bounds__(256) mt_adamw_kernel(const TensorRef* __restri
   const float gs = grad_scale ? *grad_scale : 1.0f;
   const float bc1 = 1.0f - powf(beta1, (float)t.step);
   const float bc2_sqrt = sqrtf(1.0f - powf(beta2, (float)t.step));
-  const float decay = 1.0f - lr * wd, step = lr / bc1;
+  const float decay = COUPLED ? 1.0f : 1.0f - lr * wd, step = lr / bc1;
   const bool vec = (((uintptr_t)t.p | (uintptr_t)t.g | (uintptr_t)t.m | (uintptr_t)t.v) % 16) == 0;
   size_t e4 = vec ? beg + ((end - beg) & ~(size_t)3) : beg;
   for (size_t i = beg + (size_t)threadIdx.x * 4; i < e4; i += 1024) {
     f32x4 pv = *reinterpret_cast<f32x4*>(t.p + i);
     f32x4 gv = *reinterpret_cast<const f32x4*>(t.g + i) * gs;
+    if (COUPLED) gv = gv + pv * wd;
     f32x4 mv = *reinterpret_cast<f32x4*>(t.m + i);
     f32x4 vv = *reinterpret_cast<f32x4*>(t.v + i);
     mv = mv * beta1 + gv * (1.0f - beta1);
@@ -147,7 +151,7 @@ __global__ void __launch_bounds__(256) mt_adamw_kernel(const TensorRef* __restri
     *reinterpret_cast<f32x4*>(t.v + i) = vv;
   }
   for (size_t i = e4 + threadIdx.x; i < end; i += 256) {
-    const float gg = t.g[i] * gs;
+    const float gg = COUPLED ? t.g[i] * gs + wd * t.p[i] : t.g[i] * gs;
     const float mm = t.m[i] * beta1 + gg * (1.0f - beta1);
     const float vv = t.v[i] * beta2 + gg * gg * (1.0f - beta2);
     t.p[i] = t.p[i] * decay - step * mm / (sqrtf(vv) / bc2_sqrt + eps);
@@ -209,8 +213,17 @@ DCLIP_API int dclip_mt_sumsq_f32(const void* refs, int ntensors, int total_chunk
 DCLIP_API int dclip_mt_adamw_f32(const void* refs, int ntensors, int total_chunks, float lr, float beta1, float beta2,
                                  float eps, float weight_decay, const float* grad_scale, void* stream) {
   DCLIP_REQUIRE(refs && ntensors > 0 && total_chunks > 0, "mt_adamw: bad arguments");
-  hipLaunchKernelGGL(mt_adamw_kernel, dim3(total_chunks), dim3(256), 0, (hipStream_t)stream, (const TensorRef*)refs, ntensors,
-                     lr, beta1, beta2, eps, weight_decay, grad_scale);
+  hipLaunchKernelGGL(mt_adamw_kernel<false>, dim3(total_chunks), dim3(256), 0, (hipStream_t)stream, (const TensorRef*)refs,
+                     ntensors, lr, beta1, beta2, eps, weight_decay, grad_scale);
   DCLIP_CHECK_LAUNCH("mt_adamw");
+  return DCLIP_OK;
+}
+
+DCLIP_API int dclip_mt_adam_f32(const void* refs, int ntensors, int total_chunks, float lr, float beta1, float beta2,
+                                float eps, float weight_decay, const float* grad_scale, void* stream) {
+  DCLIP_REQUIRE(refs && ntensors > 0 && total_chunks > 0, "mt_adam: bad arguments");
+  hipLaunchKernelGGL(mt_adamw_kernel<true>, dim3(total_chunks), dim3(256), 0, (hipStream_t)stream, (const TensorRef*)refs,
+                     ntensors, lr, beta1, beta2, eps, weight_decay, grad_scale);
+  DCLIP_CHECK_LAUNCH("mt_adam");
   return DCLIP_OK;
 }

@@ -30,7 +30,9 @@ def init_from_env(backend: Optional[str] = None):
         return None
     if not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC (what RCCL needs on this driver)
+        # HSA_ENABLE_IPC_MODE_LEGACY=0 (dmabuf IPC, what RCCL needs on this driver) must be in the environment BEFORE
+        # the first HIP call of the process — callers that have already touched the GPU (torch.cuda.set_device) are too
+        # late for a setdefault here.  dclip_amd/__init__.py and bench.py set it at import time.
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":
@@ -76,14 +78,39 @@ class GradSync:
         self._pending_elems = 0
         self._inflight = []         # (work, flat, [(param, offset, numel)])
         self._seen = set()
+        self.reset_stats()
+
+    # ---- bookkeeping for the bench line (bench.py "comm")
+    def reset_stats(self):
+        self._n_finish = 0
+        self._n_buckets = 0
+        self._n_bytes = 0
+        self._wait_events = []      # (before, after) event pairs around finish()'s waits, on the compute stream
+
+    def stats(self) -> dict:
+        """Per-step averages since reset_stats(): buckets all-reduced, bytes all-reduced, and the EXPOSED all-reduce
+        time (how long the compute stream sat in finish() waiting for RCCL after the backward had ended)."""
+        n = max(1, self._n_finish)
+        exposed = None
+        if self._wait_events:
+            torch.cuda.synchronize()
+            exposed = sum(a.elapsed_time(b) for a, b in self._wait_events) / n
+        return {"grad_buckets_per_step": self._n_buckets / n, "grad_allreduce_bytes_per_step": self._n_bytes / n,
+                "grad_allreduce_exposed_ms_per_step": None if exposed is None else round(exposed, 4),
+                "bucket_mb": round(self.bucket_elems * 4 / (1 << 20), 2)}
 
     # ---- called during backward
     def on_grads_ready(self, pairs):
         if self.group is None:
             return
         for p, g in pairs:
-            if g is None or id(p) not in self._ids or id(p) in self._seen:
+            if g is None or id(p) not in self._ids:
                 continue
+            if id(p) in self._seen:
+                # a second delivery within one backward (a tower applied twice) would be dropped silently and
+                # finish() would then overwrite the correctly accumulated p.grad with the first-only reduction
+                raise RuntimeError("GradSync: a parameter's gradient was delivered twice in one backward; use "
+                                   "reduce() after the backward (no overlap hook) for modules applied more than once")
             self._seen.add(id(p))
             self._pending.append((p, g))
             self._pending_elems += g.numel()
@@ -104,6 +131,8 @@ class GradSync:
         torch._foreach_copy_([flat[o:o + n] for _, o, n in layout], [g.reshape(-1) for _, g in self._pending])
         work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         self._inflight.append((work, flat, layout))
+        self._n_buckets += 1
+        self._n_bytes += flat.numel() * 4
         self._pending, self._pending_elems = [], 0
 
     # ---- called after backward
@@ -118,11 +147,19 @@ class GradSync:
                 if self._pending_elems >= self.bucket_elems:
                     self._launch()
         self._launch()
+        timed = bool(self._inflight) and self._inflight[0][1].is_cuda
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         for work, flat, layout in self._inflight:
             work.wait()
             for p, o, n in layout:                        # zero-copy: .grad becomes a view of the reduced bucket
                 if p.grad is not None:
                     p.grad = flat[o:o + n].view_as(p)
+        if timed:
+            e1.record()
+            self._wait_events.append((e0, e1))
+        self._n_finish += 1
         self._inflight, self._seen = [], set()
 
     reduce = finish

@@ -89,15 +89,37 @@ def checkpoint_filename(epoch: int, train_loss: float) -> str:
     return f"epoch-epoch={epoch:02d}-train_loss={train_loss:.2f}.ckpt"
 
 
+def _with_last_flag(iterable):
+    """(index, item, is_last) with one item of look-ahead (loaders without __len__ work too)."""
+    it = iter(iterable)
+    try:
+        prev = next(it)
+    except StopIteration:
+        return
+    i = 0
+    for cur in it:
+        yield i, prev, False
+        prev = cur
+        i += 1
+    yield i, prev, True
+
+
 class Trainer:
     """`Trainer(max_epochs, accelerator="gpu", devices=1, precision=32, gradient_clip_val=0.5,
     accumulate_grad_batches=4, callbacks=[ModelCheckpoint(...)]).fit(model)` — the subset the launcher uses."""
 
     def __init__(self, max_epochs: int = 1, gradient_clip_val: Optional[float] = 0.5, accumulate_grad_batches: int = 4,
                  checkpoint_dir: Optional[str] = None, save_top_k: int = 10, max_steps: Optional[int] = None,
-                 use_hip_graph: bool = False, **_ignored):
+                 use_hip_graph: bool = False, lr_interval: str = "epoch", **_ignored):
         """`use_hip_graph`: replay forward+backward from a captured HIP graph (dclip_amd/graph.py) — tensor batches of
-        one fixed shape, single process; the update sequence and its results are those of the eager loop."""
+        one fixed shape, single process; the update sequence and its results are those of the eager loop.
+        `lr_interval`: "epoch" (default) advances the LR schedule once per epoch — what Lightning does with the
+        reference's `return [optimizer], [scheduler]` (training/CLIP_image_distillation.py:679-682: a bare scheduler
+        gets interval="epoch"), so with the default total_steps=1000 the LR decays by 0.1 % per epoch, as written.
+        "step" advances it after every optimizer step (what the HF warm-up schedule was designed for)."""
+        if lr_interval not in ("epoch", "step"):
+            raise ValueError(f"lr_interval {lr_interval!r}")
+        self.lr_interval = lr_interval
         self.use_hip_graph = use_hip_graph
         self.max_epochs = max_epochs
         self.clip = gradient_clip_val
@@ -111,6 +133,10 @@ class Trainer:
             val_dataloaders: Optional[Iterable] = None):
         opts, scheds = model.configure_optimizers()
         opt, sched = opts[0], (scheds[0] if scheds else None)
+        # the HIP optimizer clips the global norm itself (device-side coefficient, no host sync, one pass over the grads)
+        fused_clip = bool(self.clip) and hasattr(opt, "max_grad_norm")
+        if fused_clip:
+            opt.max_grad_norm = self.clip
         train = train_dataloaders if train_dataloaders is not None else model.train_dataloader()
         val = val_dataloaders if val_dataloaders is not None else (
             model.val_dataloader() if hasattr(model, "val_dataloader") else None)
@@ -121,8 +147,13 @@ class Trainer:
             model.train()
             if graphed is None:
                 opt.zero_grad(set_to_none=True)
+            elif acc is not None:
+                torch._foreach_zero_(acc)          # nothing of the previous epoch leaks into this epoch's first update
             last = None
-            for i, batch in enumerate(train):
+            for i, batch, is_last in _with_last_flag(train):
+                # Lightning steps on every `accum`-th batch AND on the last batch of the epoch (a trailing partial
+                # group is not dropped); the divisor stays `accum` there as well
+                boundary = (i + 1) % self.accum == 0 or is_last
                 if self.use_hip_graph:
                     if graphed is None:
                         from .graph import GraphedStep
@@ -134,18 +165,18 @@ class Trainer:
                     last = loss.detach().clone()
                     if acc is not None:        # the graph ASSIGNS this micro-batch's gradients; accumulate by hand
                         torch._foreach_add_(acc, [p.grad for p in gparams], alpha=1.0 / self.accum)
-                        if (i + 1) % self.accum == 0:
+                        if boundary:
                             torch._foreach_copy_([p.grad for p in gparams], acc)
                             torch._foreach_zero_(acc)
                 else:
                     loss = model.training_step(batch)
                     (loss / self.accum).backward()
                     last = loss.detach()
-                if (i + 1) % self.accum == 0:
-                    if self.clip:
+                if boundary:
+                    if self.clip and not fused_clip:
                         torch.nn.utils.clip_grad_norm_([p for p in model.parameters() if p.grad is not None], self.clip)
                     opt.step()
-                    if sched is not None:
+                    if sched is not None and self.lr_interval == "step":
                         sched.step()
                     if graphed is None:            # graph mode: gradients live in the graph's pool and are overwritten
                         opt.zero_grad(set_to_none=True)
@@ -153,6 +184,8 @@ class Trainer:
                     model.global_step = step
                 if self.max_steps is not None and step >= self.max_steps:
                     break
+            if sched is not None and self.lr_interval == "epoch":
+                sched.step()
             if val is not None:
                 model.eval()
                 with torch.no_grad():

@@ -17,6 +17,8 @@ from . import _lib
 
 
 class FusedAdamW(torch.optim.Optimizer):
+    _entry = "dclip_mt_adamw_f32"
+
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2,
                  max_grad_norm: Optional[float] = None):
         defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
@@ -101,12 +103,22 @@ class FusedAdamW(torch.optim.Optimizer):
             coef = self._coef
         for group, (tab, nt, nchunks, _keep) in tables:
             b1, b2 = group["betas"]
-            _lib.check(lib.dclip_mt_adamw_f32(tab.data_ptr(), nt, nchunks, float(group["lr"]), float(b1), float(b2),
-                                              float(group["eps"]), float(group["weight_decay"]),
-                                              None if coef is None else coef.data_ptr(), stream), "mt_adamw")
+            _lib.check(getattr(lib, self._entry)(tab.data_ptr(), nt, nchunks, float(group["lr"]), float(b1), float(b2),
+                                                 float(group["eps"]), float(group["weight_decay"]),
+                                                 None if coef is None else coef.data_ptr(), stream), self._entry)
         # the kernel wrote the parameters through raw pointers: tell autograd / every cache keyed on tensor versions
         # (HipCLIPModel._bf16_cache) that they changed
         touched = [p for group, _t in tables for p in group["params"] if p.grad is not None]
         if touched:
             torch._C._increment_version(touched)
         return loss
+
+
+class FusedAdam(FusedAdamW):
+    """torch.optim.Adam semantics (weight decay, default 0, is L2 added to the gradient) on the same multi-tensor
+    kernel — the teacher trainer's optimizer (training/train_contrastive_teacher.py:245-248)."""
+    _entry = "dclip_mt_adam_f32"
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0,
+                 max_grad_norm: Optional[float] = None):
+        super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, max_grad_norm=max_grad_norm)

@@ -280,10 +280,15 @@ class CLIPPatchTokenizer:
             raise ValueError("crop_boxes_gpu: one box list per image")
         flat, counts = [], []
         for b, boxes in enumerate(boxes_per_image):
+            # A zero / negative-extent box (YOLO coordinates are int-truncated, training/image_tokenizer.py:56) makes
+            # PIL's crop + Resize raise inside encode_weighted_bounding_boxes; the reference catches that around the
+            # WHOLE image (training/patch_text_aggregation.py:479-486): `patch_embed_list = []`, i.e. the image keeps
+            # the single zero patch row of an image without boxes (:489-491).  Same here: count 0, no crop is cut.
+            if any(x2 <= x1 or y2 <= y1 for (x1, y1, x2, y2), _conf in boxes):
+                counts.append(0)
+                continue
             counts.append(len(boxes))
             for (x1, y1, x2, y2), _conf in boxes:
-                if x2 <= x1 or y2 <= y1:
-                    raise ValueError(f"degenerate box {(x1, y1, x2, y2)} (PIL cannot resize an empty crop either)")
                 flat.append((b, int(x1), int(y1), int(x2), int(y2)))
         rmax = max(max(counts), 1)
         regions = torch.zeros((B, rmax, 3, s, s), dtype=torch.float32, device=dev)
@@ -319,9 +324,13 @@ class CLIPPatchTokenizer:
 class PatchTextAggregation(nn.Module):
     def __init__(self, embed_dim=512, num_heads=8, similarity_threshold=0.85, projection_model_path=None,
                  faiss_index_path=None, embeddings_json_path=None, clip_model: Optional[HipCLIPModel] = None,
-                 tokenizer=None, tower_precision: str = "fp32"):
+                 tokenizer=None, tower_precision: str = "fp32", owns_clip: bool = False,
+                 text_twin: Optional[HipCLIPModel] = None):
         """`tower_precision` ("fp32" default = the reference's arithmetic; "bf16" opt-in) selects how the FROZEN
-        region / text towers multiply; the trainable cross_modal_attention always runs in fp32."""
+        region / text towers multiply; the trainable cross_modal_attention always runs in fp32.
+        `owns_clip`: the towers are this teacher's private frozen copy (they follow `.to()` / `.cuda()` although they
+        stay out of `state_dict()`).  `text_twin`: a model whose text tower held the SAME weights as `clip_model`'s
+        when this teacher was built (the student a snapshot was taken from) — see shares_text_tower_with."""
         super().__init__()
         if tower_precision not in ("fp32", "bf16"):
             raise ValueError(f"tower_precision {tower_precision!r}")
@@ -335,6 +344,10 @@ class PatchTextAggregation(nn.Module):
         self.similarity_threshold = similarity_threshold
         # plain attributes on purpose: the towers must not enter teacher.state_dict()
         object.__setattr__(self, "_clip", clip_model)
+        object.__setattr__(self, "_owns_clip", bool(owns_clip))
+        object.__setattr__(self, "_text_twin", text_twin)
+        object.__setattr__(self, "_text_twin_versions",
+                           None if text_twin is None else self._text_versions(text_twin))
         self.text_tokenizer = CLIPTextTokenizer(clip_model, tokenizer, precision=tower_precision)
         self.patch_tokenizer = CLIPPatchTokenizer(clip_model, precision=tower_precision)
         self.cross_modal_attention = CrossModalAttention(embed_dim, num_heads)
@@ -348,10 +361,27 @@ class PatchTextAggregation(nn.Module):
     def device(self):
         return self.cross_modal_attention.norm_text.weight.device
 
+    @staticmethod
+    def _text_versions(model: HipCLIPModel):
+        return tuple(p._version for p in list(model.text_model.parameters()) + [model.text_projection.weight])
+
+    def _apply(self, fn, *args, **kwargs):
+        # a private tower copy is a plain attribute (it must stay out of state_dict()), so nn.Module would not move it
+        if self._owns_clip:
+            self._clip._apply(fn, *args, **kwargs)
+        return super()._apply(fn, *args, **kwargs)
+
     def shares_text_tower_with(self, student: HipCLIPModel) -> bool:
-        """True when the teacher's frozen text tower IS the (frozen) student text tower: one forward serves both."""
-        return self._clip is student and not any(p.requires_grad for p in student.text_model.parameters()) \
+        """True when one frozen text forward serves teacher and student: the student's text tower is frozen and the
+        teacher's text tower either IS it, or is a snapshot of it and the student's text weights have not been
+        written since (parameter version counters recorded at snapshot time)."""
+        frozen = not any(p.requires_grad for p in student.text_model.parameters()) \
             and not student.text_projection.weight.requires_grad
+        if not frozen:
+            return False
+        if self._clip is student:
+            return True
+        return self._text_twin is student and self._text_twin_versions == self._text_versions(student)
 
     def load_caches(self, knn_cache_path=None):
         """:104-124 — the KNN cache only feeds the (out-of-scope) KNN tokenizer; kept so callers do not break."""

@@ -125,7 +125,11 @@ def main(args, teacher: Optional[PatchTextAggregation] = None, train_batches: Op
     if val_batches is None and getattr(args, "val_file", None) and os.path.exists(args.val_file):
         val_batches = JsonPairDataset(args.val_file, args.batch_size, shuffle=False)
 
-    optimizer = torch.optim.Adam(trainable, lr=args.learning_rate)
+    if trainable and trainable[0].is_cuda:
+        from .optim import FusedAdam
+        optimizer = FusedAdam(trainable, lr=args.learning_rate)      # optim.Adam(trainable_params, lr) (:245-248)
+    else:                                                            # CPU: argument / checkpoint plumbing only
+        optimizer = torch.optim.Adam(trainable, lr=args.learning_rate)
 
     def validate():
         teacher.eval()

@@ -312,6 +312,10 @@ int dclip_mt_chunk_elems(void);
 int dclip_mt_sumsq_f32(const void* refs, int ntensors, int total_chunks, float* partial, void* stream);
 int dclip_mt_adamw_f32(const void* refs, int ntensors, int total_chunks, float lr, float beta1, float beta2,
                        float eps, float weight_decay, const float* grad_scale, void* stream);
+/* torch.optim.Adam (L2 coupled into the gradient: g += weight_decay * p) — replaces the teacher trainer's
+ * `optim.Adam(trainable_params, lr=args.learning_rate)` (training/train_contrastive_teacher.py:245-248). */
+int dclip_mt_adam_f32(const void* refs, int ntensors, int total_chunks, float lr, float beta1, float beta2,
+                      float eps, float weight_decay, const float* grad_scale, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Small elementwise helpers used between the ops above (all fp32, 16-byte vectorised).

@@ -280,6 +280,40 @@ def distill_step(student: Dict[str, Tensor], cfg, pixel_values: Tensor, input_id
             "loss_contrastive": l_con, "image_emb": s_img, "text_emb": s_txt}
 
 
+def bridge_weight(student_dim: int, teacher_dim: int, seed: int = 0) -> Tensor:
+    """Config c5's DECLARED teacher→student bridge (no reference semantics: training/CLIP_image_distillation.py:573
+    would raise on the width mismatch; training/patch_text_aggregation.py:51 "FIX THIS IF GOING FROM VIT L TO VIT B").
+    Seeded Gaussian [student_dim, teacher_dim], std teacher_dim^-1/2 — restated here independently of the product's
+    `dclip_amd.CLIP_image_distillation.bridge_weight`; tests compare the two bit for bit."""
+    gen = torch.Generator().manual_seed(1_000_003 + int(seed))
+    return torch.randn((student_dim, teacher_dim), generator=gen, dtype=torch.float32) * float(teacher_dim) ** -0.5
+
+
+def teacher_targets(teacher: Dict[str, Tensor], tcfg, cm: Dict[str, Tensor], regions: Tensor, region_counts: Sequence[int],
+                    input_ids: Tensor, heads: int, prefix: str = "") -> Tuple[Tensor, Tensor]:
+    """The meta-teacher's two targets for one batch, from a teacher CLIP state dict `teacher` of config `tcfg`:
+    global image embedding (a5 → a8 → a6 → a7: frozen region forward in [0,1] without mean/std, zero padding to Rmax,
+    token-level text, cross-modal attention, aggregation, 0.5/0.5 — training/patch_text_aggregation.py:268-656) and
+    the sentence embedding of each caption (`aggregate_text`, training/text_tokenizer.py:220-235)."""
+    B, R = regions.shape[:2]
+    E = tcfg.projection_dim
+    embs = []
+    for b in range(B):
+        n = int(region_counts[b])
+        embs.append(vision_tower(teacher, regions[b, :n], tcfg.vision) if n > 0 else torch.zeros(0, E, dtype=regions.dtype))
+    patches = pad_regions(embs, E)
+    tokens, _n, sent = teacher_token_embeddings(teacher, input_ids, tcfg.text)
+    return global_embedding(cm, tokens, patches, heads, prefix), sent
+
+
+def distill_step_bridged(student: Dict[str, Tensor], cfg, pixel_values: Tensor, input_ids: Tensor,
+                         teacher_image_emb: Tensor, teacher_text_emb: Tensor, bridge_w: Tensor,
+                         temperature: float = 0.05) -> Dict[str, Tensor]:
+    """Config c5: `distill_step` with both (frozen, wider) teacher targets taken through the bridge first."""
+    return distill_step(student, cfg, pixel_values, input_ids, linear(teacher_image_emb, bridge_w),
+                        linear(teacher_text_emb, bridge_w), temperature)
+
+
 def teacher_step(cm: Dict[str, Tensor], text_tokens: Tensor, region_embs: Tensor, sentence_emb: Tensor,
                  heads: int = 8, temperature: float = 0.05, prefix: str = "") -> Dict[str, Tensor]:
     """Teacher-trainer step — training/train_contrastive_teacher.py:340-357: meta-teacher image embedding

@@ -470,6 +470,108 @@ def gen_step_c1(ref_con, ref_cos):
     save("step_c1.npz", **arrs)
 
 
+# ----------------------------------------------------------------------------- config c5: ViT-L/14 teacher -> ViT-B/32 student
+
+def gen_c5(pta, tt, it, ref_con, ref_cos):
+    """BASELINE config c5.  Two files from one ViT-L/14 HF model (hidden 1024, 24 layers, 16 heads, patch 14, proj 768;
+    text 768 / 12 heads / 3072):
+      towers_l14.npz  the L/14 towers at bs=2 (embeddings, per-layer statistics) — like towers_real.npz;
+      step_c5.npz     one distill step, B=2: the REFERENCE's `compute_global_embedding_batch` / `aggregate_text` run as
+                      written on shell objects over the L/14 towers and a 768-wide CrossModalAttention (12 heads), the
+                      build's DECLARED bridge 768->512 (the reference has no rule: CLIP_image_distillation.py:573 would
+                      raise), the reference's lifted losses, and an HF ViT-B/32 student (gradients of all 398 tensors)."""
+    from PIL import Image
+    from dclip_amd.CLIP_image_distillation import bridge_weight
+    tcfg = dcfg.vit_l14()
+    tsd = synth.synth_clip_state_dict(tcfg, seed=2, gain=3.0)
+    tm = hf_model(tcfg, tsd)
+    arrs = {}
+    pix = synth.synth_pixel_values(2, tcfg.vision, seed=0)
+    ids = synth.synth_input_ids(2, tcfg.text, seed=3, ragged=True)
+    with torch.no_grad():
+        vo = tm.vision_model(pixel_values=pix, output_hidden_states=True)
+        img = tm.visual_projection(vo.pooler_output)
+        to = tm.text_model(input_ids=ids, output_hidden_states=True)
+        txt = tm.text_projection(to.pooler_output)
+    arrs["l14.wsum"] = np.array(sum(float(v.double().sum()) for v in tsd.values()))
+    arrs["l14.input_ids"] = ids
+    arrs["l14.image_emb"], arrs["l14.text_emb"] = img, txt
+    for nm, hs in (("vision", vo.hidden_states), ("text", to.hidden_states)):
+        arrs[f"l14.{nm}_layer_stats"] = np.array(
+            [[float(h.double().mean()), float(h.double().std()), float(h.double().abs().max())] for h in hs])
+    arrs["l14.vision_cls_last"] = vo.last_hidden_state[:, 0, :]
+    save("towers_l14.npz", **arrs)
+
+    # ---- the step
+    m = TensorReturning(tm)
+    E = tcfg.projection_dim                                   # 768
+    cmsd = synth.synth_cross_modal_state_dict(E, seed=33)
+    B = 2
+    captions = ["a", "b"]
+    cids = synth.synth_input_ids(B, tcfg.text, seed=43, ragged=True, min_len=6)
+    id_by_caption = dict(zip(captions, cids))
+
+    class FakeTok:
+        def __call__(self, text, **kw):
+            row = id_by_caption[text]
+            n = int((row == tcfg.text.eos_token_id).int().argmax()) + 1
+            out = types.SimpleNamespace(input_ids=row[:n].unsqueeze(0), attention_mask=torch.ones(1, n, dtype=torch.long))
+            out.to = lambda dev: out
+            return out
+
+    text_tok = object.__new__(tt.CLIPTextTokenizer)
+    text_tok.tokenizer, text_tok.model, text_tok.device = FakeTok(), m, "cpu"
+    n_regions = [2, 1]
+    regions = synth.synth_regions(B, 2, tcfg.vision, seed=6)
+    queue = []
+    patch_tok = object.__new__(it.CLIPPatchTokenizer)
+    patch_tok.clip_model, patch_tok.device = m, torch.device("cpu")
+    patch_tok.patch_transform = lambda pil: queue.pop(0)
+    teacher = object.__new__(pta.PatchTextAggregation)
+    nn.Module.__init__(teacher)
+    teacher.embed_dim, teacher.device = E, torch.device("cpu")
+    teacher.text_tokenizer, teacher.patch_tokenizer = text_tok, patch_tok
+    teacher.cross_modal_attention = pta.CrossModalAttention(E, E // 64)
+    teacher.cross_modal_attention.load_state_dict(cmsd)
+    teacher.knn_cache, teacher.use_knn_projection, teacher.advanced_tokenizer = {}, False, None
+    teacher.full_resolution = False
+    with tempfile.TemporaryDirectory() as d:
+        paths, boxes = [], []
+        for b in range(B):
+            pth = os.path.join(d, f"{b}.png")
+            Image.new("RGB", (96, 80), (10 * b, 20, 30)).save(pth)
+            paths.append(pth)
+            boxes.append([((4 * r, 2 * r, 40 + 4 * r, 30 + 2 * r), 0.9 - 0.1 * r) for r in range(n_regions[b])])
+            queue.extend(regions[b, r] for r in range(n_regions[b]))
+        with torch.no_grad():
+            t_img = teacher.compute_global_embedding_batch(paths, captions, boxes).float()       # :597-600
+            t_txt = torch.stack([text_tok.aggregate_text(c) for c in captions]).float()         # :605-608
+    del tm, m, teacher
+    W = bridge_weight(512, E, 0)
+    scfg = dcfg.vit_b32()
+    ssd = synth.synth_clip_state_dict(scfg, seed=0, gain=3.0)
+    sm = TensorReturning(hf_model(scfg, ssd))
+    sm.m.train()
+    spix = synth.synth_pixel_values(B, scfg.vision, seed=8)
+    # the student tokenises the same captions with ITS processor; both CLIP tokenizers share one vocabulary, so the
+    # ids are the same rows
+    s_img = sm.get_image_features(pixel_values=spix).float()
+    s_txt = sm.get_text_features(input_ids=cids).float()
+    bt_img, bt_txt = F.linear(t_img, W), F.linear(t_txt, W)
+    l_img, l_txt, l_con = ref_cos(s_img, bt_img), ref_cos(s_txt, bt_txt), ref_con(s_img, s_txt)
+    loss = l_img + l_txt + 1.0 * l_con
+    grads = all_grads(sm.m, loss)
+    out = {"input_ids": cids, "n_regions": np.array(n_regions), "teacher_image_768": t_img, "teacher_text_768": t_txt,
+           "bridged_image": bt_img, "bridged_text": bt_txt, "bridge_checksum": np.array(float(W.double().sum())),
+           "image_emb": s_img, "text_emb": s_txt, "loss_image": l_img, "loss_text": l_txt, "loss_contrastive": l_con,
+           "loss": loss, "teacher_seed": np.array(2), "cm_seed": np.array(33), "student_seed": np.array(0),
+           "regions_seed": np.array(6), "pixel_seed": np.array(8),
+           "wsum_student": np.array(sum(float(v.double().sum()) for v in ssd.values()))}
+    for k, v in grad_probes(grads).items():
+        out[f"gradprobe.{k}"] = v
+    save("step_c5.npz", **out)
+
+
 # ----------------------------------------------------------------------------- eval consumers (SURVEY §8f-1)
 
 def gen_eval():
@@ -592,6 +694,8 @@ def main():
         gen_towers_real()
     if not which or "step_c1" in which:
         gen_step_c1(ref_con, ref_cos)
+    if not which or "c5" in which:
+        gen_c5(pta, tt, it, ref_con, ref_cos)
     if not which or "eval" in which:
         gen_eval()
     if not which or "data" in which:

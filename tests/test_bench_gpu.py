@@ -30,3 +30,36 @@ def test_bench_prints_one_json_line_with_roofline_and_cpu_baseline():
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["value"] > 0 and c["cores"] >= 1 and "sample" in c
     assert "workload" in d["config"] and "model" not in d["config"]
+
+
+def test_bare_gpus_2_self_launches_its_ranks():
+    """`python bench.py --gpus 2` with no launcher: bench.py starts the two ranks itself as a child torch.distributed.run
+    and relays rank 0's line.  On the one-GPU test box the ranks rendezvous over gloo and share the card
+    (DCLIP_DIST_BACKEND=gloo); on a multi-GPU node the same call runs over RCCL."""
+    import torch
+    env = dict(os.environ, DCLIP_BENCH_CPU_SECONDS="1")
+    env.pop("WORLD_SIZE", None), env.pop("RANK", None), env.pop("LOCAL_RANK", None)
+    if torch.cuda.device_count() < 2:
+        env["DCLIP_DIST_BACKEND"] = "gloo"
+    p = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--batch", "16"], capture_output=True, text=True, timeout=900, env=env, cwd=REPO)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 32 and d["config"]["parallelism"] == "dp2"
+    c = d["comm"]
+    assert c["ranks"] == 2 and c["grad_buckets_per_step"] >= 1 and c["grad_allreduce_bytes_per_step"] > 3e8
+    assert "fwd_bwd_ms_per_step" in d and "cpu_baseline" not in d
+
+
+def test_bench_extra_legs_and_same_regime_cpu_baseline():
+    env = dict(os.environ, DCLIP_BENCH_CPU_SECONDS="1")
+    p = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--steps", "3", "--warmup", "1", "--batch", "16"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=REPO)
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = json.loads([l for l in p.stdout.splitlines() if l.strip()][0])
+    assert 0 < d["fwd_bwd_ms_per_step"] <= d["ms_per_step"] * 1.05        # optimizer excluded (SURVEY §8d)
+    assert d["graph_ms_per_step"] > 0, d.get("graph_error")
+    assert "north_star" in d["cpu_baseline"]["sample"] and "c1" in d["cpu_baseline_c1"]["sample"]
+    assert d["roofline"]["traffic_source"].startswith("profiles/")

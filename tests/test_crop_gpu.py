@@ -61,3 +61,31 @@ def test_tokenizer_gpu_crops_equal_host_crops():
         for r, (box, _) in enumerate(bl):
             assert torch.equal(regions[b, r].cpu(), tok.patch_transform(imgs[b].crop(box)))
     assert float(regions[1].abs().sum()) == 0.0
+
+
+def test_degenerate_box_takes_the_reference_fallback():
+    """A zero-width / zero-height box (YOLO coordinates are int-truncated) makes PIL raise inside the reference's
+    encode_weighted_bounding_boxes; the reference catches it for the WHOLE image and uses the single zero patch row
+    (training/patch_text_aggregation.py:479-491).  No exception here either: that image gets count 0."""
+    from PIL import Image
+    from dclip_amd import config as dcfg, synth
+    from dclip_amd.clip_model import from_hf_state_dict
+    from dclip_amd.patch_text_aggregation import PatchTextAggregation
+    dev = torch.device("cuda:0")
+    cfg = dcfg.tiny()
+    clip = from_hf_state_dict(cfg, synth.synth_clip_state_dict(cfg, seed=7, gain=4.0), device=dev)
+    teacher = PatchTextAggregation(embed_dim=cfg.projection_dim, num_heads=1, clip_model=clip).to(dev)
+    rng = np.random.default_rng(2)
+    imgs = [Image.fromarray(rng.integers(0, 256, (90, 120, 3), dtype=np.uint8)) for _ in range(3)]
+    good = ((4, 2, 60, 50), 0.9)
+    bad_boxes = [[good, ((30, 10, 30, 40), 0.8)], [good], [((5, 9, 50, 9), 0.5)]]       # zero width; fine; zero height
+    ref_boxes = [[], [good], []]                                                        # what the fallback amounts to
+    regions, counts = teacher.patch_tokenizer.crop_boxes_gpu(imgs, bad_boxes)
+    assert counts.tolist() == [0, 1, 0]
+    regions2, counts2 = teacher.patch_tokenizer.crop_boxes_gpu(imgs, ref_boxes)
+    assert counts2.tolist() == [0, 1, 0] and torch.equal(regions[:, :1], regions2[:, :1])
+    ids = synth.synth_input_ids(3, cfg.text, seed=3, ragged=True, min_len=4).to(dev)
+    with torch.no_grad():
+        a = teacher.compute_global_embedding_tensors(regions, ids, counts)
+        b = teacher.compute_global_embedding_tensors(regions2, ids, counts2)
+    assert torch.equal(a, b) and bool(torch.isfinite(a).all())

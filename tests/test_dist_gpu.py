@@ -83,3 +83,51 @@ def test_two_ranks_equal_single_process(overlap):
         assert abs(out[r]["loss"] - float(loss.detach())) < 1e-5 * abs(float(loss.detach()))
         assert float((out[r]["g_proj"] - g_proj).abs().max()) < 2e-5 * float(g_proj.abs().max())
         assert float((out[r]["g_qkv"] - g_qkv).abs().max()) < 2e-5 * float(g_qkv.abs().max())
+
+
+def _rccl_worker(rank, world, port, B, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from dclip_amd import dist as ddist, functional
+    group = ddist.init_from_env("nccl")                    # RCCL over xGMI, one GPU per rank
+    dev = torch.device("cuda", rank)
+    cfg, mod = _build(dev, group)
+    full = _batch(cfg, B)
+    Bl = B // world
+    shard = {k: v[rank * Bl:(rank + 1) * Bl].contiguous() for k, v in full.items()}
+    trainable = [p for p in mod.parameters() if p.requires_grad]
+    sync = ddist.GradSync(trainable, group, bucket_mb=0.05)
+    functional.set_grad_ready_hook(sync.on_grads_ready)
+    share = mod.training_step(shard)
+    share.backward()
+    sync.finish()
+    functional.set_grad_ready_hook(None)
+    tot = share.detach().clone()
+    dist.all_reduce(tot, group=group)
+    torch.cuda.synchronize()
+    st = sync.stats()
+    out[rank] = dict(loss=float(tot), g_proj=mod.student.visual_projection.weight.grad.cpu(),
+                     g_qkv=mod.student.vision_model.encoder.layers[0].self_attn.qkv_proj.weight.grad.cpu(),
+                     buckets=st["grad_buckets_per_step"])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="the RCCL path needs two GPUs (the driver's multi-GPU node)")
+def test_two_ranks_over_rccl_equal_single_process():
+    """backend "nccl" (= RCCL): embedding all-gather + LSE all-gather + bucketed gradient all-reduce launched from
+    inside the backward, one GPU per rank; N-rank loss / gradients == single process on the concatenated batch."""
+    B, world = 8, 2
+    out = mp.Manager().dict()
+    mp.spawn(_rccl_worker, args=(world, _free_port(), B, out), nprocs=world, join=True)
+    dev = torch.device("cuda:0")
+    cfg, mod = _build(dev, None)
+    loss = mod.training_step(_batch(cfg, B))
+    loss.backward()
+    g_proj = mod.student.visual_projection.weight.grad.cpu()
+    g_qkv = mod.student.vision_model.encoder.layers[0].self_attn.qkv_proj.weight.grad.cpu()
+    for r in range(world):
+        assert abs(out[r]["loss"] - float(loss.detach())) < 1e-5 * abs(float(loss.detach()))
+        assert float((out[r]["g_proj"] - g_proj).abs().max()) < 2e-5 * float(g_proj.abs().max())
+        assert float((out[r]["g_qkv"] - g_qkv).abs().max()) < 2e-5 * float(g_qkv.abs().max())
+        assert out[r]["buckets"] >= 2

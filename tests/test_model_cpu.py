@@ -134,3 +134,61 @@ def test_towers_fail_loudly_without_gpu():
     m = HipCLIPModel(cfg)
     with pytest.raises((ValueError, RuntimeError)):
         m.get_image_features(pixel_values=torch.zeros(1, 3, cfg.vision.image_size, cfg.vision.image_size))
+
+
+class _ToyModule(lightning_lite.LightningLikeModule):
+    """Host-logic stand-in for the Trainer tests: loss = w * x, so each micro-batch contributes x to w.grad."""
+
+    def __init__(self, total_steps=1000):
+        super().__init__()
+        self.w = torch.nn.Parameter(torch.zeros(()))
+        self.total = total_steps
+
+    def training_step(self, batch, batch_idx=0):
+        return self.w * batch
+
+    def configure_optimizers(self):
+        opt = torch.optim.SGD([self.w], lr=1.0)
+        sched = torch.optim.lr_scheduler.LambdaLR(opt, lambda s: max(0.0, (self.total - s) / self.total))
+        return [opt], [sched]
+
+
+def test_trainer_steps_on_trailing_micro_batches_and_schedules_per_epoch():
+    """Lightning semantics the reference relies on (training/CLIP_image_distill_training.py:36-45,
+    training/CLIP_image_distillation.py:679-682): accumulate 4 with a step on the LAST batch of an epoch, and a bare
+    scheduler advances once per EPOCH."""
+    mod = _ToyModule(total_steps=1000)
+    batches = [torch.tensor(float(v)) for v in (1, 2, 3, 4, 5, 6)]          # 6 batches: groups [1..4] and [5, 6]
+    tr = lightning_lite.Trainer(max_epochs=2, gradient_clip_val=None, accumulate_grad_batches=4)
+    tr.fit(mod, batches, None)
+    lr0, lr1 = 1.0, 0.999                                                   # epoch 0, epoch 1 (one scheduler tick)
+    want = -(lr0 * (10 / 4 + 11 / 4) + lr1 * (10 / 4 + 11 / 4))
+    assert abs(float(mod.w) - want) < 1e-6, (float(mod.w), want)
+    assert mod.global_step == 4
+    # per-step interval on request: the LR decays with every optimizer step
+    mod2 = _ToyModule(total_steps=4)
+    lightning_lite.Trainer(max_epochs=1, gradient_clip_val=None, accumulate_grad_batches=1,
+                           lr_interval="step").fit(mod2, batches[:4], None)
+    assert abs(float(mod2.w) + (1 * 1.0 + 2 * 0.75 + 3 * 0.5 + 4 * 0.25)) < 1e-6
+
+
+def test_default_teacher_is_a_frozen_snapshot_of_the_student():
+    """The reference teacher owns separate CLIP instances that never train (training/image_tokenizer.py:25,
+    training/text_tokenizer.py:21): the default teacher must not alias the (training) student towers."""
+    cfg = dcfg.tiny()
+    student = HipCLIPModel(cfg)
+    hp = argparse.Namespace(learning_rate=1e-3, warmup_steps=0, total_steps=10, train_batch_size=2, eval_batch_size=2)
+    mod = CLIPImageDistillation(hp, student, None, freeze_mode="north_star")
+    tclip = mod.teacher._clip
+    assert tclip is not student
+    assert not any(p.requires_grad for p in tclip.parameters())
+    tw = tclip.vision_model.encoder.layers[0].mlp.fc1.weight
+    sw = student.vision_model.encoder.layers[0].mlp.fc1.weight
+    assert tw.data_ptr() != sw.data_ptr() and torch.equal(tw, sw)
+    assert not any(k.startswith("teacher._clip") or "vision_model" in k for k in mod.teacher.state_dict())
+    assert mod.teacher.shares_text_tower_with(student)          # frozen text tower, untouched since the snapshot
+    with torch.no_grad():
+        student.text_projection.weight.add_(1.0)                # an in-place update of the student's text weights ...
+    assert not mod.teacher.shares_text_tower_with(student)      # ... ends the sharing (teacher keeps its own copy)
+    mod.set_freeze_mode("as_written")
+    assert not mod.teacher.shares_text_tower_with(student)

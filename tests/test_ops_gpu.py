@@ -304,6 +304,25 @@ def test_fused_adamw_and_clip_match_torch(dev):
         assert relerr(q, p) < 1e-5 or float((q.cpu() - p).abs().max()) < 1e-7
 
 
+@pytest.mark.parametrize("wd", [0.0, 0.03])
+def test_fused_adam_matches_torch_adam(dev, wd):
+    """The teacher trainer's optimizer: torch.optim.Adam (training/train_contrastive_teacher.py:245-248), L2 coupled."""
+    from dclip_amd.optim import FusedAdam
+    shapes = [(1536, 512), (1536,), (512, 512), (5,)]
+    ps = [torch.nn.Parameter(rnd(s, 10 + i)) for i, s in enumerate(shapes)]
+    mine = [torch.nn.Parameter(p.detach().clone().to(dev)) for p in ps]
+    ref_opt = torch.optim.Adam(ps, lr=1e-2, weight_decay=wd)
+    my_opt = FusedAdam(mine, lr=1e-2, weight_decay=wd)
+    for step in range(4):
+        for j, (p, q) in enumerate(zip(ps, mine)):
+            g = rnd(p.shape, 200 * step + j, 0.05)
+            p.grad, q.grad = g.clone(), g.clone().to(dev)
+        ref_opt.step()
+        my_opt.step()
+    for p, q in zip(ps, mine):
+        assert relerr(q, p) < 1e-5 or float((q.cpu() - p).abs().max()) < 1e-7
+
+
 @pytest.mark.parametrize("M,N,K,split", [(768, 768, 12800, 0), (3072, 768, 12800, 0), (2304, 768, 12800, 4), (132, 64, 77, 1),
                                          (768, 3072, 256, 0), (100, 36, 1000, 3)])
 def test_gemm_wgrad_rowsum_is_the_bias_gradient(M, N, K, split):

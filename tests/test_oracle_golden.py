@@ -250,3 +250,60 @@ def test_step_c1(golden):
     for k, gr in zip(keys, grads):
         gr = torch.zeros_like(p[k]) if gr is None else gr
         check_probe(gr, k, g[f"gradprobe.{k}"], rtol=2e-3)
+
+
+# ---------------------------------------------------------------- config c5 (ViT-L/14 teacher -> ViT-B/32 student)
+
+@pytest.mark.timeout(900)
+def test_towers_l14_forward(golden):
+    """The oracle's towers at ViT-L/14 size (hidden 1024 / 24 layers / 16 heads / patch 14 / proj 768; text 768/12/3072)
+    against HF CLIPModel(CLIPConfig(...)) outputs — the c5 teacher."""
+    g = golden("towers_l14.npz")
+    cfg = dcfg.vit_l14()
+    sd = synth.synth_clip_state_dict(cfg, seed=2, gain=3.0)
+    assert abs(wsum(sd) - float(g["l14.wsum"])) < 1e-6 * abs(float(g["l14.wsum"]))
+    pix = synth.synth_pixel_values(2, cfg.vision, seed=0)
+    ids = T(g["l14.input_ids"])
+    with torch.no_grad():
+        img, vh = O.vision_tower(sd, pix, cfg.vision, return_hidden=True)
+        txt = O.text_tower(sd, ids, cfg.text)
+    close(img, g["l14.image_emb"], rtol=1e-3, atol=1e-4)
+    close(txt, g["l14.text_emb"], rtol=1e-3, atol=1e-4)
+    stats = np.array([[float(h.double().mean()), float(h.double().std()), float(h.double().abs().max())] for h in vh])
+    np.testing.assert_allclose(stats, g["l14.vision_layer_stats"], rtol=1e-3, atol=1e-5)
+
+
+@pytest.mark.timeout(900)
+def test_step_c5(golden):
+    """One c5 step: the golden's teacher targets come from the REFERENCE's compute_global_embedding_batch /
+    aggregate_text over L/14 towers; the bridge is the build's declared rule; losses are the reference's."""
+    from dclip_amd.CLIP_image_distillation import bridge_weight
+    g = golden("step_c5.npz")
+    tcfg, scfg = dcfg.vit_l14(), dcfg.vit_b32()
+    W = O.bridge_weight(scfg.projection_dim, tcfg.projection_dim, 0)
+    assert torch.equal(W, bridge_weight(scfg.projection_dim, tcfg.projection_dim, 0))        # product == restatement
+    assert abs(float(W.double().sum()) - float(g["bridge_checksum"])) < 1e-9
+    tsd = synth.synth_clip_state_dict(tcfg, seed=int(g["teacher_seed"]), gain=3.0)
+    cm = synth.synth_cross_modal_state_dict(tcfg.projection_dim, seed=int(g["cm_seed"]))
+    ids = T(g["input_ids"])
+    B = ids.shape[0]
+    regions = synth.synth_regions(B, 2, tcfg.vision, seed=int(g["regions_seed"]))
+    with torch.no_grad():
+        t_img, t_txt = O.teacher_targets(tsd, tcfg, cm, regions, g["n_regions"], ids, heads=tcfg.projection_dim // 64)
+    close(t_img, g["teacher_image_768"], rtol=1e-3, atol=1e-4)
+    close(t_txt, g["teacher_text_768"], rtol=1e-3, atol=1e-4)
+    del tsd
+    ssd = synth.synth_clip_state_dict(scfg, seed=int(g["student_seed"]), gain=3.0)
+    assert abs(wsum(ssd) - float(g["wsum_student"])) < 1e-6 * abs(float(g["wsum_student"]))
+    p = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in ssd.items()}
+    pix = synth.synth_pixel_values(B, scfg.vision, seed=int(g["pixel_seed"]))
+    out = O.distill_step_bridged(p, scfg, pix, ids, t_img, t_txt, W)
+    close(out["image_emb"], g["image_emb"], rtol=1e-3, atol=1e-4)
+    close(out["text_emb"], g["text_emb"], rtol=1e-3, atol=1e-4)
+    for k in ("loss_image", "loss_text", "loss_contrastive", "loss"):
+        close(out[k], g[k], rtol=1e-4)
+    keys = [k for k in p if k != "logit_scale"]
+    grads = torch.autograd.grad(out["loss"], [p[k] for k in keys], allow_unused=True)
+    for k, gr in zip(keys, grads):
+        gr = torch.zeros_like(p[k]) if gr is None else gr
+        check_probe(gr, k, g[f"gradprobe.{k}"], rtol=2e-3)

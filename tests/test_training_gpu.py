@@ -268,3 +268,35 @@ def test_teacher_trainer_on_reference_batches(tmp_path):
     assert os.path.exists(args.output_path)
     sd = torch.load(args.output_path, weights_only=True)
     assert len(sd) == 12
+
+
+def test_default_teacher_targets_do_not_move_with_the_student():
+    """with teacher=None the meta-teacher must not encode regions with the TRAINING student tower.
+    The reference teacher owns separate, never-updated CLIP instances (training/image_tokenizer.py:25,
+    training/text_tokenizer.py:21): the teacher embedding of a fixed batch is bit-identical before and after updates."""
+    from dclip_amd.CLIP_image_distillation import CLIPImageDistillation
+    from dclip_amd.optim import FusedAdamW
+    dev = torch.device("cuda:0")
+    cfg, clip = _clip(dev)
+    hp = argparse.Namespace(learning_rate=5e-3, warmup_steps=0, total_steps=100, train_batch_size=6, eval_batch_size=6)
+    for mode in ("north_star", "as_written"):
+        cfg, clip = _clip(dev)
+        mod = CLIPImageDistillation(hp, clip, None, freeze_mode=mode).to(dev)
+        assert mod.teacher._clip is not mod.student
+        batch = {"pixel_values": synth.synth_pixel_values(6, cfg.vision, seed=0).to(dev),
+                 "input_ids": synth.synth_input_ids(6, cfg.text, seed=3, ragged=True).to(dev),
+                 "regions": synth.synth_regions(6, 2, cfg.vision, seed=4).to(dev)}
+        with torch.no_grad():
+            before = mod.teacher.compute_global_embedding_tensors(batch["regions"], batch["input_ids"]).clone()
+            sent_before = mod.teacher.last_sentence_embedding.clone()
+        w0 = mod.student.vision_model.encoder.layers[0].self_attn.qkv_proj.weight.detach().clone()
+        opt = FusedAdamW([p for p in mod.parameters() if p.requires_grad], lr=5e-3, max_grad_norm=0.5)
+        for _ in range(3):
+            mod.training_step(batch).backward()
+            opt.step()
+            opt.zero_grad(set_to_none=True)
+        assert not torch.equal(mod.student.vision_model.encoder.layers[0].self_attn.qkv_proj.weight.detach(), w0)
+        with torch.no_grad():
+            after = mod.teacher.compute_global_embedding_tensors(batch["regions"], batch["input_ids"])
+        assert torch.equal(before, after), mode
+        assert torch.equal(sent_before, mod.teacher.last_sentence_embedding), mode
