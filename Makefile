@@ -16,7 +16,15 @@ $(CSRC)/build/%.o: $(CSRC)/%.hip $(CSRC)/common.h include/dclip_hip.h
 $(LIB): $(OBJS)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS)
 
+# Diagnostic library with in-kernel time stamps in the GEMM (tools/gemm_stamps.py); never loaded by the product.
+STAMPLIB := tools/ab/libdclip_hip_stamps.so
+stamps: $(STAMPLIB)
+$(STAMPLIB): $(OBJS) $(CSRC)/gemm_f32.hip
+	@mkdir -p tools/ab
+	$(HIPCC) $(HIPFLAGS) -DDCLIP_GEMM_STAMPS -c $(CSRC)/gemm_f32.hip -o $(CSRC)/build/gemm_f32_stamps.o
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(filter-out $(CSRC)/build/gemm_f32.o,$(OBJS)) $(CSRC)/build/gemm_f32_stamps.o
+
 clean:
 	rm -rf $(CSRC)/build $(LIB)
 
-.PHONY: all clean
+.PHONY: all clean stamps

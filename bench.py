@@ -300,7 +300,7 @@ def main():
         else:
             for p in trainable:
                 p.grad = None
-        return loss
+        return loss.detach()            # keep no reference to the autograd graph (a later HIP-graph capture needs none)
 
     def timed(n, fn):
         """n calls of fn bracketed by synchronize (+ barrier) on both sides; MAX over ranks, seconds."""
@@ -330,6 +330,8 @@ def main():
     timer.enabled = graphed is None
     elapsed, last = timed(args.steps, step)            # ---- THE timed region: exactly K steps
     timer.enabled = False
+    last_loss = float(last.detach())
+    del last
     comm = sync.stats() if sync is not None else None
 
     # ---- extra legs, outside the contract's timed region ("optimizer excluded and reported separately")
@@ -413,7 +415,7 @@ def main():
             "config": {"workload": wl + ("fwd+bwd only" if opt is None else "fwd+bwd + clip-norm 0.5 + AdamW")
                                    + (", fwd+bwd replayed from a HIP graph" if graphed is not None else ""),
                        "global_batch": world * B, "parallelism": f"dp{world}",
-                       "loss": float(last.detach())},
+                       "loss": last_loss},
             "roofline": {"bound": "mfma", "kernel": "gemm_f32_kernel (v_mfma_f32_32x32x2_f32)",
                          "achieved": None if achieved is None else round(achieved, 2),
                          "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",

@@ -46,9 +46,34 @@ struct GemmParams {
   float* part_s;         // mode 1: [tiles_n*WN][M] sum exp(z - max)
   int offset;            // column of row i's positive = i + offset
   const int32_t* gt;     // mode 3: per-row ground-truth column, excluded from the count (nullptr = row index)
+#ifdef DCLIP_GEMM_STAMPS
+  int dbg;               // diagnostic ablations (WRONG results): 1 no epilogue, 2 no DMA in the K loop, 4 no K-loop barrier,
+                         // 8 DMA pieces fetched out of range (issue + zero fill, no memory traffic)
+#endif
 };
 
 enum { MODE_GEMM = 0, MODE_LSE = 1, MODE_DZ = 2, MODE_RANK = 3 };
+
+// Diagnostic build only (`make stamps` -> tools/ab/libdclip_hip_stamps.so, never the product library): per workgroup,
+// shader-clock stamps at kernel entry / first barrier / end of the K loop / exit, the 100 MHz real-time clock at entry
+// and exit (comparable across CUs), where it ran, and wave 0's cycles in the end-of-tile vmcnt wait and barrier.
+// Stamp values go to a buffer of their own.  tools/gemm_stamps.py, tools/gemm_ablate.py.
+#ifdef DCLIP_GEMM_STAMPS
+__device__ unsigned long long* g_stamps = nullptr;
+#define GEMM_STAMP_V(slot, value)                                                              \
+  do {                                                                                         \
+    if (threadIdx.x == 0 && g_stamps)                                                          \
+      g_stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + (slot)] = (value);          \
+  } while (0)
+#define GEMM_STAMP(slot) GEMM_STAMP_V(slot, __builtin_amdgcn_s_memtime())
+#define GEMM_STAMP_RT(slot) GEMM_STAMP_V(slot, __builtin_amdgcn_s_memrealtime())
+#define GEMM_DBG(bit) (p.dbg & (bit))
+#else
+#define GEMM_STAMP_V(slot, value) do {} while (0)
+#define GEMM_STAMP(slot) do {} while (0)
+#define GEMM_STAMP_RT(slot) do {} while (0)
+#define GEMM_DBG(bit) false
+#endif
 
 __device__ __forceinline__ void apply_epilogue_store(const GemmParams& p, int row, int col, float v) {
   v *= p.alpha;
@@ -96,6 +121,8 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) gemm_f32_kernel(GemmParams p)
   const int wm = wave / WN, wn = wave % WN;
   const int l31 = lane & 31, half = lane >> 5;
 
+  GEMM_STAMP(0);
+  GEMM_STAMP_RT(4);
   const int nwg = p.tiles_m * p.tiles_n;
   // Each XCD walks a contiguous range of `swz`; inside it tiles are visited in groups of GROUP_M tile-rows, column
   // by column, so the ~64 workgroups resident on one XCD cover an ~8x8 patch of tiles: every A / B panel slice
@@ -342,6 +369,9 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) gemm_f32_kernel(GemmParams p)
   // ~79 B/clk/CU and is shared by the three co-resident workgroups) — one DMA piece behind each of MFMA steps
   // 1..NCH (so every piece has >= 16 - NCH steps to land), then vmcnt(0) and the barrier.  Issuing on every other
   // step instead measured +0.3 % rather than +1.1 %.
+#ifdef DCLIP_GEMM_STAMPS
+  unsigned long long st_vm = 0, st_bar = 0;   // cycles wave 0 spent in the end-of-tile vmcnt(0) wait / in the barrier
+#endif
   auto compute_and_dma = [&](int buf, int kt) {
     const float* a = As + buf * BM * BK;
     const float* b = Bs + buf * BN * BK;
@@ -361,12 +391,19 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) gemm_f32_kernel(GemmParams p)
         const int step = g * 4 + r;
         if (step >= 1 && step - 1 < NCH) {
           __builtin_amdgcn_sched_barrier(0);
-          dma_chunk(buf ^ 1, kt + 1, step - 1);
+          if (GEMM_DBG(8)) dma_chunk(buf ^ 1, 0x3fffff, step - 1);
+          else if (!GEMM_DBG(2)) dma_chunk(buf ^ 1, kt + 1, step - 1);
           __builtin_amdgcn_sched_barrier(0);
         }
       }
     }
+#ifdef DCLIP_GEMM_STAMPS
+    const unsigned long long w0 = __builtin_amdgcn_s_memtime();
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    st_vm += __builtin_amdgcn_s_memtime() - w0;
+#else
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's pieces of the next tile have landed
+#endif
   };
 
   const bool k_ragged = (A_KMAJOR || B_KMAJOR) && (kspan % BK) != 0;  // only the last tile can be partial
@@ -374,12 +411,19 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) gemm_f32_kernel(GemmParams p)
   if (k_ragged && nk == 1) store_tile(0, 0, true);
   else store_tile(0, 0, false);
   __syncthreads();
+  GEMM_STAMP(1);
   int kt = 0;
   const int n_steady = nk - 1 - (k_ragged ? 1 : 0);  // tiles whose successor is a full tile
   for (; kt < n_steady; ++kt) {
     if (DMA && !do_rs) compute_and_dma(kt & 1, kt);   // the row sums need the chunks in registers: tile column 0 keeps them
     else compute_and_stage(kt & 1, kt);
+#ifdef DCLIP_GEMM_STAMPS
+    const unsigned long long b0 = __builtin_amdgcn_s_memtime();
+    if (!GEMM_DBG(4)) __syncthreads();
+    st_bar += __builtin_amdgcn_s_memtime() - b0;
+#else
     __syncthreads();
+#endif
   }
   for (; kt < nk; ++kt) {
     const int buf = kt & 1;
@@ -391,6 +435,23 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) gemm_f32_kernel(GemmParams p)
     }
     __syncthreads();
   }
+  GEMM_STAMP(2);
+#ifdef DCLIP_GEMM_STAMPS
+  {
+    const unsigned hw = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11));     // HW_REG_HW_ID, 32 bits
+    const unsigned xcc = __builtin_amdgcn_s_getreg((20) | (0 << 6) | (3 << 11));    // HW_REG_XCC_ID[3:0]
+    GEMM_STAMP_V(6, ((unsigned long long)xcc << 32) | hw);
+    // slot 7: tile index (20 bits) | vmcnt-wait cycles (22 bits) | barrier-wait cycles (22 bits), both saturating
+    const unsigned long long vmc = st_vm > 0x3FFFFF ? 0x3FFFFF : st_vm, brc = st_bar > 0x3FFFFF ? 0x3FFFFF : st_bar;
+    GEMM_STAMP_V(7, (unsigned long long)(swz & 0xFFFFF) | (vmc << 20) | (brc << 42));
+  }
+  if (GEMM_DBG(1)) {          // no epilogue at all: keep the accumulators alive with a store that never executes
+    if (p.alpha == 12345.678f) p.C[threadIdx.x] = acc[0][0][0] + acc[MT - 1][NT - 1][15];
+    GEMM_STAMP(3);
+    GEMM_STAMP_RT(5);
+    return;
+  }
+#endif
 
   if (do_rs) {   // all LDS reads of the K loop are behind the last barrier: reuse the tile space
     *reinterpret_cast<f32x4*>(lds + tid * 4) = rs4;
@@ -534,6 +595,8 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) gemm_f32_kernel(GemmParams p)
       if (epi & DCLIP_EPI_ACCUM) v += *reinterpret_cast<const f32x4*>(p.C + off);
       *reinterpret_cast<f32x4*>(p.C + off) = v;
     }
+    GEMM_STAMP(3);
+    GEMM_STAMP_RT(5);
     return;
   }
   const bool has_side0 = epi & (DCLIP_EPI_RESIDUAL | DCLIP_EPI_DGELU);
@@ -592,6 +655,8 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) gemm_f32_kernel(GemmParams p)
         }
       }
     }
+  GEMM_STAMP(3);
+  GEMM_STAMP_RT(5);
 }
 
 // Sums split-K slabs in fixed order, then applies the epilogue.  One float4 per thread.
@@ -695,6 +760,17 @@ Plan make_plan(int M, int N, int K, int layout, int split_k) {
 
 }  // namespace
 
+#ifdef DCLIP_GEMM_STAMPS
+// [workgroups][8] uint64 on the device, or nullptr to stop stamping (diagnostic library only)
+DCLIP_API int dclip_debug_set_gemm_stamps(void* buf) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &buf, sizeof(buf)) == hipSuccess ? DCLIP_OK : DCLIP_ELAUNCH;
+}
+DCLIP_API void dclip_debug_gemm_plan(int M, int N, int K, int layout, int split_k, int* out4) {
+  Plan pl = make_plan(M, N, K, layout, split_k);
+  out4[0] = pl.bm, out4[1] = pl.bn, out4[2] = pl.splits, out4[3] = pl.k_per_split;
+}
+#endif
+
 DCLIP_API size_t dclip_gemm_f32_workspace(int M, int N, int K, int layout, int split_k) {
   Plan pl = make_plan(M, N, K, layout, split_k);
   return pl.splits > 1 ? (size_t)pl.splits * ((size_t)M * N + M) * sizeof(float) : 0;   // C slabs + A_ROWSUM slabs
@@ -730,6 +806,9 @@ DCLIP_API int dclip_gemm_f32(const float* A, const float* B, float* C, const flo
   GemmParams p{A, B, C, bias, residual, aux, M, N, K, lda, ldb, ldc, epilogue, alpha,
                cdiv(M, pl.bm), cdiv(N, pl.bn), pl.k_per_split, nullptr, nullptr, group_m_default(),
                MODE_GEMM, nullptr, nullptr, nullptr, nullptr, 0, nullptr};
+#ifdef DCLIP_GEMM_STAMPS
+  p.dbg = getenv("DCLIP_GEMM_DBG") ? atoi(getenv("DCLIP_GEMM_DBG")) : 0;
+#endif
   if (pl.splits > 1) {
     const size_t need = (size_t)pl.splits * ((size_t)M * N + M) * sizeof(float);
     if (!workspace || workspace_bytes < need) {
