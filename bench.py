@@ -61,7 +61,8 @@ class GemmTimer:
     figure for the dominant kernel."""
 
     def __init__(self):
-        self.records = []
+        self.records = []          # dclip_gemm_f32 launches
+        self.records16 = []        # dclip_gemm_bf16 launches (frozen towers / bf16 student)
         self.enabled = False
 
     def install(self):
@@ -83,19 +84,37 @@ class GemmTimer:
             return out
 
         ops.gemm = timed_gemm
+        inner16 = ops.gemm_bf16
+
+        def timed_gemm_bf16(a, w, **kw):
+            if not timer.enabled:
+                return inner16(a, w, **kw)
+            M = a.shape[0]
+            N = kw.get("n") or w.shape[0]
+            K = kw.get("k") or min(a.shape[1], w.shape[1])
+            e0 = torch.cuda.Event(enable_timing=True)
+            e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = inner16(a, w, **kw)
+            e1.record()
+            timer.records16.append((2.0 * M * N * K, e0, e1, (M, N, K, "bf16")))
+            return out
+
+        ops.gemm_bf16 = timed_gemm_bf16
 
     def by_shape(self):
         """{(M,N,K,layout): (launches, total ms, TFLOP/s)} — tuning aid (DCLIP_BENCH_SHAPES=1 prints it to stderr)."""
         agg = {}
-        for fl, e0, e1, key in self.records:
+        for fl, e0, e1, key in self.records + self.records16:
             n, ms, f = agg.get(key, (0, 0.0, 0.0))
             agg[key] = (n + 1, ms + e0.elapsed_time(e1), f + fl)
         return {k: (n, ms, f / (ms * 1e-3) / 1e12) for k, (n, ms, f) in agg.items()}
 
-    def summary(self):
-        flops = sum(r[0] for r in self.records)
-        ms = sum(r[1].elapsed_time(r[2]) for r in self.records)
-        return flops, ms, len(self.records)
+    def summary(self, bf16: bool = False):
+        recs = self.records16 if bf16 else self.records
+        flops = sum(r[0] for r in recs)
+        ms = sum(r[1].elapsed_time(r[2]) for r in recs)
+        return flops, ms, len(recs)
 
 
 def cpu_baseline(seconds: float = 12.0, regime: str = "north_star"):
@@ -189,6 +208,9 @@ def main():
                          "declared frozen projection) and bf16 teacher towers unless --tower-precision says otherwise")
     ap.add_argument("--regions", type=int, default=8)
     ap.add_argument("--teacher-model", default=None, choices=list(dcfg.NAMED))
+    ap.add_argument("--student-precision", default="fp32", choices=["fp32", "bf16"],
+                    help="bf16: the student's vision tower multiplies in bf16 (forward, dgrad, wgrad; fp32 master weights) — "
+                         "what BASELINE quotes c3 / c5 in.  The benched config c2 is fp32")
     ap.add_argument("--tower-precision", default=None, choices=["fp32", "bf16"],
                     help="c3 / c5: GEMM input precision of the FROZEN teacher towers (student is always fp32); default "
                          "fp32 for c3, bf16 for c5")
@@ -241,7 +263,7 @@ def main():
     hp = argparse.Namespace(learning_rate=1e-6, warmup_steps=0, total_steps=10 ** 6, train_batch_size=args.batch,
                             eval_batch_size=args.batch)
     module = CLIPImageDistillation(hp, student, None, teacher=teacher, freeze_mode="north_star",
-                                   process_group=group).to(dev)
+                                   process_group=group, student_precision=args.student_precision).to(dev)
     trainable = [p for p in module.parameters() if p.requires_grad]
     opt = None if args.no_optimizer else optim.FusedAdamW(trainable, lr=hp.learning_rate, max_grad_norm=0.5)
     sync = ddist.GradSync(trainable, group) if world > 1 else None
@@ -343,7 +365,7 @@ def main():
             extra["fwd_bwd_ms_per_step"] = round(el * 1e3 / n_x, 3)
             extra["fwd_bwd_images_per_s"] = round(world * B * n_x / el, 2)
             extra["optimizer_ms_per_step"] = round(elapsed * 1e3 / args.steps - el * 1e3 / n_x, 3)
-        if world == 1:
+        if world == 1 and not meta:          # the meta-teacher sizes its token padding on the host: not capturable
             try:
                 from dclip_amd.graph import GraphedStep
                 for p_ in trainable:
@@ -394,7 +416,8 @@ def main():
             wl = (f"BASELINE config c2: {cfg.name} distill step, bs={B}/GPU, 224x224 + {T}-token synthetic pairs, "
                   f"contrastive+cosine loss, fp32, vision trainable / text frozen (north_star regime), ")
         else:
-            wl = (f"BASELINE config {args.workload} (extra, not the benched config): {cfg.name} student fp32 + meta-teacher "
+            wl = (f"BASELINE config {args.workload} (extra, not the benched config): {cfg.name} student "
+                  f"{args.student_precision} + meta-teacher "
                   f"in the step ({args.regions} region crops/img through a frozen {tcfg.name} tower with "
                   f"{args.tower_precision} GEMM inputs, token-level text, cross-modal attention + aggregation"
                   + (f", {tcfg.projection_dim}->{cfg.projection_dim} teacher bridge" if module.teacher_bridge is not None
@@ -410,7 +433,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "bf16" if args.student_precision == "bf16" else "f32",
             "data": "synthetic",
             "config": {"workload": wl + ("fwd+bwd only" if opt is None else "fwd+bwd + clip-norm 0.5 + AdamW")
                                    + (", fwd+bwd replayed from a HIP graph" if graphed is not None else ""),
@@ -435,15 +458,28 @@ def main():
                               "flops_per_image": step_flops_per_image(cfg, T)},
         }
         line.update(extra)
+        g16 = timer.summary(bf16=True) if not args.no_gemm_events else (0.0, 0.0, 0)
+        if g16[2] and graphed is None:
+            # bf16 GEMM family (frozen teacher towers, bf16 student): its own roofline against the dense bf16 MFMA peak
+            line["roofline_bf16"] = {"bound": "mfma", "kernel": "gemm_bf16_dma_kernel / gemm_bf16_kernel (v_mfma_f32_32x32x16_bf16)",
+                                     "achieved": round(g16[0] / (g16[1] * 1e-3) / 1e12, 2), "peak": 2500.0, "unit": "TFLOP/s",
+                                     "frac": round(g16[0] / (g16[1] * 1e-3) / 1e12 / 2500.0, 4),
+                                     "launches_per_step": g16[2] // max(1, args.steps),
+                                     "gemm_ms_per_step": round(g16[1] / max(1, args.steps), 3),
+                                     "gemm_flops_per_step": g16[0] / max(1, args.steps)}
+        if args.student_precision == "bf16" and args.workload == "c2":
+            line["config"]["workload"] = line["config"]["workload"].replace(
+                "fp32, vision", "STUDENT VISION TOWER IN bf16 (not the benched precision), vision")
         if meta:
             # mixed-precision floor: student flops at the fp32 matrix peak + frozen-teacher flops at the peak of the
             # precision they were multiplied in (bf16 dense 2500 TF/s, MI355X_MICROARCH.md)
             tpeak = 2500.0 if args.tower_precision == "bf16" else PEAK_F32_MFMA_TFLOPS
-            t_min_ms = (step_flops / PEAK_F32_MFMA_TFLOPS + teacher_flops / tpeak) / 1e9
+            speak = 2500.0 if args.student_precision == "bf16" else PEAK_F32_MFMA_TFLOPS
+            t_min_ms = (step_flops / speak + teacher_flops / tpeak) / 1e9
             line["roofline_step"] = {"bound": "mfma", "unit": "ms", "floor_ms": round(t_min_ms, 3),
                                      "frac": round(t_min_ms / ms_per_step, 4),
                                      "student_flops_per_image": step_flops / B, "teacher_flops_per_image": teacher_flops / B,
-                                     "teacher_peak_tflops": tpeak}
+                                     "teacher_peak_tflops": tpeak, "student_peak_tflops": speak}
         if comm is not None:
             line["comm"] = dict(comm, backend=backend, ranks=dist.get_world_size(group),
                                 embedding_all_gather_bytes_per_rank=2 * B * cfg.projection_dim * 4)

@@ -72,8 +72,15 @@ def _as_hip_model(clip_model) -> HipCLIPModel:
 
 class CLIPImageDistillation(LightningLikeModule):
     def __init__(self, hparams, clip_model, clip_preprocess=None, teacher=None, freeze_mode: str = "north_star",
-                 process_group=None, contrastive_teacher_path: Optional[str] = None):
+                 process_group=None, contrastive_teacher_path: Optional[str] = None, student_precision: str = "fp32"):
+        """`student_precision`: "fp32" (default: the reference's `precision=32`,
+        training/CLIP_image_distill_training.py:40, and the benched config c2) or "bf16" — the student's VISION tower
+        multiplies in bf16 (forward, dgrad, wgrad) with fp32 master weights, fp32 accumulation and fp32
+        LayerNorm / softmax / losses: what BASELINE configs c3 / c5 quote ("bf16 MFMA")."""
         super().__init__()
+        if student_precision not in ("fp32", "bf16"):
+            raise ValueError(f"student_precision {student_precision!r}")
+        self.student_precision = student_precision
         self.save_hyperparameters(hparams, ignore="clip_model")
         self.student = _as_hip_model(clip_model)
         self.preprocess = clip_preprocess
@@ -193,7 +200,7 @@ class CLIPImageDistillation(LightningLikeModule):
                 teacher_image = self.teacher_bridge(teacher_image)
             if teacher_text is not None and teacher_text.shape[1] != self.student.config.projection_dim:
                 teacher_text = self.teacher_bridge(teacher_text)
-        student_image = self.student.get_image_features(pixel_values=images).float()
+        student_image = self.student.get_image_features(pixel_values=images, precision=self.student_precision).float()
         loss_image = self.cosine_distillation_loss(student_image, teacher_image)
         shared_sentence = None
         if ran_teacher and self.teacher.shares_text_tower_with(self.student) \

@@ -177,7 +177,10 @@ class HipCLIPModel(nn.Module):
         p = self.vision_params()
         if precision == "bf16":
             if torch.is_grad_enabled() and any(t.requires_grad for t in p.tensors()):
-                raise RuntimeError("precision='bf16' is a forward-only path for frozen towers: call it under torch.no_grad()")
+                # TRAINING in bf16 (configs c3 / c5): forward, dgrad and wgrad GEMMs on the bf16 MFMA kernels, fp32
+                # master weights and fp32 everything else (engine.vision_fwd_bf16_train)
+                return functional.VisionTowerBf16Fn.apply(pixel_values.float(), v, v.num_hidden_layers, self._bf16_cache(),
+                                                          *p.tensors())
             pd = engine.VisionParams.from_tensors([t.detach() for t in p.tensors()], v.num_hidden_layers)
             return engine.vision_fwd_bf16(pd, pixel_values.float().contiguous(), v, self._bf16_cache())
         if precision != "fp32":

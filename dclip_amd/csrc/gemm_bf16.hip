@@ -29,7 +29,17 @@ struct GemmBf16Params {
   int epilogue;
   int out_bf16;
   int tiles_m, tiles_n;
+  unsigned short* aux;   // bf16 [M][ldc]: GELU writes the pre-activation there, DGELU reads it (training path)
 };
+
+// 4 consecutive bf16 at p (8-byte aligned) -> 4 floats
+__device__ __forceinline__ f32x4 load_bf16x4(const unsigned short* p) {
+  const u16x4 b = *reinterpret_cast<const u16x4*>(p);
+  f32x4 v;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) v[e] = __builtin_bit_cast(float, (unsigned int)b[e] << 16);
+  return v;
+}
 
 __device__ __forceinline__ unsigned short f32_to_bf16_bits(float x) {
   __bf16 b = (__bf16)x;  // v_cvt_pk_bf16_f32: round-to-nearest-even, NaN stays NaN
@@ -200,11 +210,22 @@ __global__ void __launch_bounds__(256, 2) gemm_bf16_kernel(GemmBf16Params p) {
     if (row >= p.M || col >= p.N) continue;  // N % 4 == 0: a chunk is inside or outside as a whole
     f32x4 v = *reinterpret_cast<const f32x4*>(ct + lr * BN + lc);
     if (p.epilogue & DCLIP_EPI_BIAS) v += *reinterpret_cast<const f32x4*>(p.bias + col);
+    const size_t off = (size_t)row * p.ldc + col;
     if (p.epilogue & DCLIP_EPI_GELU) {
+      if (p.aux) {
+        u16x4 h = {f32_to_bf16_bits(v[0]), f32_to_bf16_bits(v[1]), f32_to_bf16_bits(v[2]), f32_to_bf16_bits(v[3])};
+        *reinterpret_cast<u16x4*>(p.aux + off) = h;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = __builtin_bit_cast(float, (unsigned int)h[e] << 16);   // gelu of what was saved
+      }
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] = quick_gelu_f(v[e]);
     }
-    const size_t off = (size_t)row * p.ldc + col;
+    if (p.epilogue & DCLIP_EPI_DGELU) {
+      const f32x4 h = load_bf16x4(p.aux + off);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] *= quick_gelu_grad_f(h[e]);
+    }
     if (p.epilogue & DCLIP_EPI_RESIDUAL) v += *reinterpret_cast<const f32x4*>(p.residual + off);
     if (p.out_bf16) {
       u16x4 o = {f32_to_bf16_bits(v[0]), f32_to_bf16_bits(v[1]), f32_to_bf16_bits(v[2]), f32_to_bf16_bits(v[3])};
@@ -371,11 +392,22 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_bf16_dma_kernel(GemmBf16Par
       if (row >= p.M || col >= p.N) continue;
       f32x4 v = *reinterpret_cast<const f32x4*>(ct + lr * BN + lc);
       if (p.epilogue & DCLIP_EPI_BIAS) v += *reinterpret_cast<const f32x4*>(p.bias + col);
+      const size_t off = (size_t)row * p.ldc + col;
       if (p.epilogue & DCLIP_EPI_GELU) {
+        if (p.aux) {
+          u16x4 h = {f32_to_bf16_bits(v[0]), f32_to_bf16_bits(v[1]), f32_to_bf16_bits(v[2]), f32_to_bf16_bits(v[3])};
+          *reinterpret_cast<u16x4*>(p.aux + off) = h;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = __builtin_bit_cast(float, (unsigned int)h[e] << 16);
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = quick_gelu_f(v[e]);
       }
-      const size_t off = (size_t)row * p.ldc + col;
+      if (p.epilogue & DCLIP_EPI_DGELU) {
+        const f32x4 h = load_bf16x4(p.aux + off);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] *= quick_gelu_grad_f(h[e]);
+      }
       if (p.epilogue & DCLIP_EPI_RESIDUAL) v += *reinterpret_cast<const f32x4*>(p.residual + off);
       if (p.out_bf16) {
         u16x4 o = {f32_to_bf16_bits(v[0]), f32_to_bf16_bits(v[1]), f32_to_bf16_bits(v[2]), f32_to_bf16_bits(v[3])};
@@ -420,7 +452,8 @@ __global__ void __launch_bounds__(256) cast_bf16_kernel(const float* __restrict_
 template <int NC>
 __global__ void __launch_bounds__(256) ln_fwd_bf16_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, unsigned short* __restrict__ y,
-                                                          int rows, int D, float eps) {
+                                                          int rows, int D, float eps, float* __restrict__ mean_out,
+                                                          float* __restrict__ rstd_out) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -445,6 +478,10 @@ __global__ void __launch_bounds__(256) ln_fwd_bf16_kernel(const float* __restric
     }
   }
   const float rs = rsqrtf(wave_sum(q) / (float)D + eps);
+  if (mean_out && lane == 0) {
+    mean_out[row] = mu;
+    rstd_out[row] = rs;
+  }
 #pragma unroll
   for (int c = 0; c < NC; ++c) {
     int i = lane + 64 * c;
@@ -465,12 +502,20 @@ inline int grid_for(size_t work) {
 
 DCLIP_API int dclip_gemm_bf16(const void* A, const void* W, void* C, const float* bias, const float* residual, int M, int N,
                               int K, int lda, int ldw, int ldc, int epilogue, int out_bf16, void* stream) {
+  return dclip_gemm_bf16_ex(A, W, C, bias, residual, nullptr, M, N, K, lda, ldw, ldc, epilogue, out_bf16, stream);
+}
+
+DCLIP_API int dclip_gemm_bf16_ex(const void* A, const void* W, void* C, const float* bias, const float* residual, void* aux,
+                                 int M, int N, int K, int lda, int ldw, int ldc, int epilogue, int out_bf16, void* stream) {
   DCLIP_REQUIRE(A && W && C, "gemm_bf16: null operand");
   DCLIP_REQUIRE(M > 0 && N > 0 && K > 0, "gemm_bf16: bad shape M=%d N=%d K=%d", M, N, K);
   DCLIP_REQUIRE(lda % 8 == 0 && ldw % 8 == 0 && lda >= K && ldw >= K, "gemm_bf16: lda/ldw must be multiples of 8 and >= K");
   DCLIP_REQUIRE(N % 4 == 0 && ldc % 4 == 0 && ldc >= N, "gemm_bf16: N / ldc must be multiples of 4");
   DCLIP_REQUIRE(((uintptr_t)A | (uintptr_t)W | (uintptr_t)C) % 16 == 0, "gemm_bf16: operands must be 16-byte aligned");
-  DCLIP_REQUIRE(!(epilogue & ~(DCLIP_EPI_BIAS | DCLIP_EPI_GELU | DCLIP_EPI_RESIDUAL)), "gemm_bf16: unsupported epilogue bits");
+  DCLIP_REQUIRE(!(epilogue & ~(DCLIP_EPI_BIAS | DCLIP_EPI_GELU | DCLIP_EPI_DGELU | DCLIP_EPI_RESIDUAL)),
+                "gemm_bf16: unsupported epilogue bits");
+  DCLIP_REQUIRE(!(epilogue & DCLIP_EPI_DGELU) || (aux && !(epilogue & DCLIP_EPI_GELU)), "gemm_bf16: DGELU needs aux (and no GELU)");
+  DCLIP_REQUIRE(!aux || (uintptr_t)aux % 8 == 0, "gemm_bf16: aux must be 8-byte aligned");
   DCLIP_REQUIRE(!(epilogue & DCLIP_EPI_BIAS) || bias, "gemm_bf16: BIAS without bias");
   DCLIP_REQUIRE(!(epilogue & DCLIP_EPI_RESIDUAL) || (residual && !out_bf16), "gemm_bf16: RESIDUAL needs an fp32 output");
   hipStream_t st = (hipStream_t)stream;
@@ -480,7 +525,8 @@ DCLIP_API int dclip_gemm_bf16(const void* A, const void* W, void* C, const float
   // projection of 2048 crops): one workgroup per CU cannot overlap that with the next tile's MFMAs.
   static const int big_min = getenv("DCLIP_BF16_BIG_MIN") ? atoi(getenv("DCLIP_BF16_BIG_MIN")) : 128;   // tuning aid
   if (K % BKH == 0 && (long)cdiv(M, 256) * cdiv(N, 256) >= big_min) {
-    GemmBf16Params pb{(const __bf16*)A, (const __bf16*)W, C, bias, residual, M, N, K, lda, ldw, ldc, epilogue, out_bf16, 0, 0};
+    GemmBf16Params pb{(const __bf16*)A, (const __bf16*)W, C, bias, residual, M, N, K, lda, ldw, ldc, epilogue, out_bf16, 0, 0,
+                      (unsigned short*)aux};
     launch_dma<256, 256, 2, 4>(pb, st);
     DCLIP_CHECK_LAUNCH("gemm_bf16.dma");
     return DCLIP_OK;
@@ -488,7 +534,7 @@ DCLIP_API int dclip_gemm_bf16(const void* A, const void* W, void* C, const float
   const bool small = (long)cdiv(M, 128) * cdiv(N, 128) < 256;  // fewer tiles than CUs: use the finer tile
   const int bm = small ? 64 : 128, bn = bm;
   GemmBf16Params p{(const __bf16*)A, (const __bf16*)W, C, bias, residual, M, N, K, lda, ldw, ldc, epilogue, out_bf16,
-                   cdiv(M, bm), cdiv(N, bn)};
+                   cdiv(M, bm), cdiv(N, bn), (unsigned short*)aux};
   const size_t lds = (size_t)2 * (bm + bn) * BKH * 2;
   if (small) hipLaunchKernelGGL((gemm_bf16_kernel<64, 64>), dim3(p.tiles_m * p.tiles_n), dim3(256), lds, st, p);
   else hipLaunchKernelGGL((gemm_bf16_kernel<128, 128>), dim3(p.tiles_m * p.tiles_n), dim3(256), lds, st, p);
@@ -508,13 +554,19 @@ DCLIP_API int dclip_cast_f32_bf16(const float* x, void* y, int rows, int cols, i
 
 DCLIP_API int dclip_layernorm_fwd_bf16(const float* x, const float* gamma, const float* beta, void* y, int rows, int D,
                                        float eps, void* stream) {
+  return dclip_layernorm_fwd_bf16_stats(x, gamma, beta, y, nullptr, nullptr, rows, D, eps, stream);
+}
+
+DCLIP_API int dclip_layernorm_fwd_bf16_stats(const float* x, const float* gamma, const float* beta, void* y, float* mean,
+                                             float* rstd, int rows, int D, float eps, void* stream) {
   DCLIP_REQUIRE(x && gamma && beta && y, "layernorm_fwd_bf16: null pointer");
+  DCLIP_REQUIRE((mean == nullptr) == (rstd == nullptr), "layernorm_fwd_bf16: mean and rstd go together");
   DCLIP_REQUIRE(rows > 0 && D > 0 && D % 4 == 0 && D <= 2048, "layernorm_fwd_bf16: bad D=%d", D);
   dim3 grid(cdiv(rows, 4)), block(256);
   hipStream_t st = (hipStream_t)stream;
   const int nc = cdiv(D / 4, 64);
   unsigned short* yy = (unsigned short*)y;
-#define LN16(NC) hipLaunchKernelGGL((ln_fwd_bf16_kernel<NC>), grid, block, 0, st, x, gamma, beta, yy, rows, D, eps)
+#define LN16(NC) hipLaunchKernelGGL((ln_fwd_bf16_kernel<NC>), grid, block, 0, st, x, gamma, beta, yy, rows, D, eps, mean, rstd)
   if (nc <= 1) LN16(1);
   else if (nc == 2) LN16(2);
   else if (nc == 3) LN16(3);

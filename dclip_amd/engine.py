@@ -322,6 +322,163 @@ def vision_fwd_bf16(p: VisionParams, pixel_values: torch.Tensor, cfg, cache: dic
     return ops.gemm(pooled, p.proj_w, ops.LAYOUT_NT)          # [B,D] x [P,D]: tiny, kept in exact fp32
 
 
+# --------------------------------------------------------------------------------------------- bf16 TRAINING (vision)
+# The student's vision tower with bf16 GEMM inputs in forward, dgrad AND wgrad (BASELINE configs c3 / c5 quote the step
+# in bf16; opt-in `precision="bf16"` with gradients enabled).  fp32 master weights (bf16 copies W and W^T are rebuilt
+# when the optimizer has stepped), fp32 accumulation, fp32 residual stream / LayerNorm statistics / softmax; the
+# attention core itself runs on the fp32 kernels (2 % of the FLOPs, HBM-bound).  The weight-gradient product
+# dW[out,in] = dY^T X is computed by the same C = A W^T kernel on token-contiguous operands (dY^T, X^T) written by
+# ops.transpose_bf16.  The patch embedding, the pooled LayerNorm and the projection stay fp32; every encoder layer is
+# run at full size (the CLS-row pruning of the fp32 schedule would keep a full-size fp32 qkv projection).
+
+def _w16t(cache: dict, key: str, w: torch.Tensor) -> torch.Tensor:
+    """bf16 W^T [in, ld >= out] of an nn.Linear weight [out, in]: the `W` operand of the dgrad GEMM dX = dY (W^T)^T."""
+    t = cache.get(key + ".T")
+    if t is None:
+        t = ops.transpose_bf16(w.detach().reshape(w.shape[0], -1).contiguous())
+        cache[key + ".T"] = t
+    return t
+
+
+def layer_fwd_bf16_train(x, p: LayerParams, c: dict, pre: str, B: int, S: int, H: int, causal: bool, eps: float):
+    ln1, m1, r1 = ops.layernorm_fwd_bf16(x, p.ln1_w, p.ln1_b, eps, save_stats=True)
+    qkv = ops.gemm_bf16(ln1, _w16(c, pre + "qkv", p.qkv_w), bias=p.qkv_b)            # fp32 out: the attention core is fp32
+    attn, lse = ops.attention_fwd(qkv, B, S, H, causal)
+    attn16 = ops.cast_bf16(attn)
+    x1 = ops.gemm_bf16(attn16, _w16(c, pre + "out", p.out_w), bias=p.out_b, residual=x)
+    ln2, m2, r2 = ops.layernorm_fwd_bf16(x1, p.ln2_w, p.ln2_b, eps, save_stats=True)
+    g16, h16 = ops.gemm_bf16(ln2, _w16(c, pre + "fc1", p.fc1_w), bias=p.fc1_b, gelu=True, out_bf16=True, save_preact=True)
+    x2 = ops.gemm_bf16(g16, _w16(c, pre + "fc2", p.fc2_w), bias=p.fc2_b, residual=x1)
+    return x2, (x, m1, r1, ln1, qkv, attn, attn16, lse, x1, m2, r2, ln2, h16, g16)
+
+
+def _wgrad_bf16(dyT, xT, M: int, need_w: bool):
+    """dW [out, in] fp32 = dY^T X from the token-contiguous bf16 operands dY^T [out, ld], X^T [in, ld]."""
+    return ops.gemm_bf16(dyT, xT, k=M) if need_w else None
+
+
+def layer_bwd_bf16(dx2, p: LayerParams, c: dict, pre: str, saved, B: int, S: int, H: int, causal: bool, need: Dict[str, bool]):
+    x, m1, r1, ln1, qkv, attn, attn16, lse, x1, m2, r2, ln2, h16, g16 = saved
+    M = x.shape[0]
+    D = x.shape[1]
+    gr: Dict[str, torch.Tensor] = {}
+    # ---- fc2
+    dx2T, dx2_16 = ops.transpose_bf16(dx2, want_copy=True)
+    if need.get("fc2_w"):
+        gr["fc2_w"] = _wgrad_bf16(dx2T, ops.transpose_bf16(g16), M, True)
+    if need.get("fc2_b"):
+        gr["fc2_b"] = ops.colsum(dx2)
+    dh16 = ops.gemm_bf16(dx2_16, _w16t(c, pre + "fc2", p.fc2_w), k=D, dgelu_of=h16, out_bf16=True)       # [M, I]
+    del dx2T, dx2_16
+    # ---- fc1
+    dhT = ops.transpose_bf16(dh16)
+    if need.get("fc1_w"):
+        gr["fc1_w"] = _wgrad_bf16(dhT, ops.transpose_bf16(ln2), M, True)
+    if need.get("fc1_b"):
+        gr["fc1_b"] = ops.rowsum_bf16(dhT, M)
+    dln2 = ops.gemm_bf16(dh16, _w16t(c, pre + "fc1", p.fc1_w), k=dh16.shape[1])                          # [M, D] fp32
+    del dh16, dhT
+    want_ln2 = bool(need.get("ln2_w") or need.get("ln2_b"))
+    dx1, dg, db = ops.layernorm_bwd(dln2, x1, p.ln2_w, m2, r2, dresidual=dx2, need_param_grads=want_ln2)
+    if want_ln2:
+        gr["ln2_w"], gr["ln2_b"] = dg, db
+    # ---- out_proj
+    dx1T, dx1_16 = ops.transpose_bf16(dx1, want_copy=True)
+    if need.get("out_w"):
+        gr["out_w"] = _wgrad_bf16(dx1T, ops.transpose_bf16(attn16), M, True)
+    if need.get("out_b"):
+        gr["out_b"] = ops.colsum(dx1)
+    dattn = ops.gemm_bf16(dx1_16, _w16t(c, pre + "out", p.out_w), k=D)                                   # [M, D] fp32
+    del dx1T, dx1_16
+    dqkv = ops.attention_bwd(qkv, attn, dattn, lse, B, S, H, causal)                                     # fp32 [M, 3D]
+    # ---- qkv projection
+    dqkvT, dqkv16 = ops.transpose_bf16(dqkv, want_copy=True)
+    if need.get("qkv_w"):
+        gr["qkv_w"] = _wgrad_bf16(dqkvT, ops.transpose_bf16(ln1), M, True)
+    if need.get("qkv_b"):
+        gr["qkv_b"] = ops.colsum(dqkv)
+    dln1 = ops.gemm_bf16(dqkv16, _w16t(c, pre + "qkv", p.qkv_w), k=3 * D)
+    del dqkv, dqkvT, dqkv16
+    want_ln1 = bool(need.get("ln1_w") or need.get("ln1_b"))
+    dx, dg, db = ops.layernorm_bwd(dln1, x, p.ln1_w, m1, r1, dresidual=dx1, need_param_grads=want_ln1)
+    if want_ln1:
+        gr["ln1_w"], gr["ln1_b"] = dg, db
+    return dx, gr
+
+
+def vision_fwd_bf16_train(p: VisionParams, pixel_values: torch.Tensor, cfg, cache: dict):
+    """get_image_features with gradients, bf16 GEMM inputs in the encoder layers."""
+    v = cfg
+    B = pixel_values.shape[0]
+    S, D, H = v.seq_len, v.hidden_size, v.num_attention_heads
+    cols = ops.im2col(pixel_values, v.patch_size)
+    patch = ops.gemm(cols, p.patch_w.view(D, -1), ops.LAYOUT_NT)
+    emb = ops.vision_assemble_fwd(patch, p.class_embedding, p.pos, B, S, D)
+    del patch
+    x, m0, r0 = ops.layernorm_fwd(emb, p.pre_w, p.pre_b, v.layer_norm_eps, save_stats=True)
+    saved_layers = []
+    for li, lp in enumerate(p.layers):
+        x, sv = layer_fwd_bf16_train(x, lp, cache, f"v{li}.", B, S, H, False, v.layer_norm_eps)
+        saved_layers.append(sv)
+    cls_tok = ops.gather_rows(x, None, B, S, D)
+    pooled, mp, rp = ops.layernorm_fwd(cls_tok, p.post_w, p.post_b, v.layer_norm_eps, save_stats=True)
+    out = ops.gemm(pooled, p.proj_w, ops.LAYOUT_NT)
+    return out, (cols, emb, m0, r0, saved_layers, cls_tok, mp, rp, pooled)
+
+
+def vision_bwd_bf16(p: VisionParams, saved, d_out: torch.Tensor, cfg, need: List[bool], cache: dict, on_ready=None):
+    """Backward of vision_fwd_bf16_train; same contract as vision_bwd."""
+    v = cfg
+    cols, emb, m0, r0, saved_layers, cls_tok, mp, rp, pooled = saved
+    B = cls_tok.shape[0]
+    S, D, H = v.seq_len, v.hidden_size, v.num_attention_heads
+    names = p.names()
+    needd = dict(zip(names, need))
+    grads: Dict[str, Optional[torch.Tensor]] = {n: None for n in names}
+    if needd["proj_w"]:
+        grads["proj_w"] = ops.gemm(d_out, pooled, ops.LAYOUT_TN)
+    dpooled = ops.gemm(d_out, p.proj_w, ops.LAYOUT_NN)
+    want = needd["post_w"] or needd["post_b"]
+    dcls, dg, db = ops.layernorm_bwd(dpooled, cls_tok, p.post_w, mp, rp, need_param_grads=want)
+    if want:
+        grads["post_w"], grads["post_b"] = dg, db
+    if on_ready is not None:
+        on_ready({n: grads[n] for n in VisionParams.TAIL if grads[n] is not None})
+    lowest = None
+    for n in names:
+        if needd[n] and n not in VisionParams.TAIL:
+            li = -1 if n in VisionParams.HEAD else int(n.split(".")[1])
+            lowest = li if lowest is None else min(lowest, li)
+    if lowest is None:
+        return [grads[n] for n in names]
+    dx = ops.scatter_rows(dcls, None, B, S, D)
+    for i in range(len(p.layers) - 1, max(lowest, 0) - 1, -1):
+        lneed = {f: needd[f"layers.{i}.{f}"] for f in LayerParams.FIELDS}
+        dx, gr = layer_bwd_bf16(dx, p.layers[i], cache, f"v{i}.", saved_layers[i], B, S, H, False, lneed)
+        saved_layers[i] = None
+        for f, t in gr.items():
+            grads[f"layers.{i}.{f}"] = t
+        if on_ready is not None:
+            on_ready({f"layers.{i}.{f}": t for f, t in gr.items()})
+    if lowest < 0:
+        want = needd["pre_w"] or needd["pre_b"]
+        demb, dg, db = ops.layernorm_bwd(dx, emb, p.pre_w, m0, r0, need_param_grads=want)
+        if want:
+            grads["pre_w"], grads["pre_b"] = dg, db
+        if needd["pos"] or needd["class_embedding"]:
+            dpos = ops.colsum(demb.view(B, S * D))
+            if needd["pos"]:
+                grads["pos"] = dpos.view(S, D)
+            if needd["class_embedding"]:
+                grads["class_embedding"] = dpos[:D].clone()
+        if needd["patch_w"]:
+            dpatch = ops.vision_assemble_bwd(demb, B, S, D)
+            grads["patch_w"] = ops.gemm(dpatch, cols, ops.LAYOUT_TN).view_as(p.patch_w)
+        if on_ready is not None:
+            on_ready({n: grads[n] for n in VisionParams.HEAD if grads[n] is not None})
+    return [grads[n] for n in names]
+
+
 # --------------------------------------------------------------------------------------------- text tower
 
 @dataclass

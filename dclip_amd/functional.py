@@ -48,6 +48,33 @@ class VisionTowerFn(torch.autograd.Function):
         return (None, None, None, *grads)
 
 
+class VisionTowerBf16Fn(torch.autograd.Function):
+    """VisionTowerFn with bf16 GEMM inputs in forward, dgrad and wgrad (engine.vision_fwd_bf16_train); `cache` holds the
+    bf16 weight copies (HipCLIPModel._bf16_cache: rebuilt when a parameter version changes)."""
+
+    @staticmethod
+    def forward(ctx, pixel_values, cfg, n_layers, cache, *params):
+        p = engine.VisionParams.from_tensors([_c(t.detach()) for t in params], n_layers)
+        out, saved = engine.vision_fwd_bf16_train(p, _c(pixel_values.detach()), cfg, cache)
+        ctx.p, ctx.saved, ctx.cfg, ctx.cache = p, saved, cfg, cache
+        ctx.param_refs = params
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        if ctx.saved is None:
+            raise RuntimeError("VisionTowerBf16Fn.backward called twice")
+        on_ready = None
+        if _GRAD_READY_HOOK is not None:
+            by_name = dict(zip(ctx.p.names(), ctx.param_refs))
+            hook = _GRAD_READY_HOOK
+            on_ready = lambda named: hook([(by_name[n], g) for n, g in named.items()])      # noqa: E731
+        grads = engine.vision_bwd_bf16(ctx.p, ctx.saved, _c(d_out), ctx.cfg, list(ctx.needs_input_grad[4:]), ctx.cache,
+                                       on_ready)
+        ctx.saved = None
+        return (None, None, None, None, *grads)
+
+
 class TextTowerFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, input_ids, cfg, n_layers, *params):

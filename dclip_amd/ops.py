@@ -586,15 +586,56 @@ def cast_bf16(x: torch.Tensor, pad_to: int = 8) -> torch.Tensor:
     return y
 
 
-def layernorm_fwd_bf16(x, gamma, beta, eps: float) -> torch.Tensor:
+def layernorm_fwd_bf16(x, gamma, beta, eps: float, save_stats: bool = False):
+    """nn.LayerNorm with fp32 statistics and a bf16 result; with `save_stats` returns (y, mean, rstd) for the backward."""
     lib = _lib.load()
     _f32(x, "x"), _f32(gamma, "gamma"), _f32(beta, "beta")
     D = x.shape[-1]
     rows = x.numel() // D
     y = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
-    _lib.check(lib.dclip_layernorm_fwd_bf16(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), rows, D,
-                                            float(eps), _stream()), "layernorm_fwd_bf16")
-    return y
+    if not save_stats:
+        _lib.check(lib.dclip_layernorm_fwd_bf16(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), rows, D,
+                                                float(eps), _stream()), "layernorm_fwd_bf16")
+        return y
+    mean = torch.empty((rows,), dtype=torch.float32, device=x.device)
+    rstd = torch.empty((rows,), dtype=torch.float32, device=x.device)
+    _lib.check(lib.dclip_layernorm_fwd_bf16_stats(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(),
+                                                  mean.data_ptr(), rstd.data_ptr(), rows, D, float(eps), _stream()),
+               "layernorm_fwd_bf16_stats")
+    return y, mean, rstd
+
+
+def transpose_bf16(x: torch.Tensor, want_copy: bool = False):
+    """x [rows, cols] fp32 or bf16 -> x^T [cols, ld] bf16 with ld = rows rounded up to 8 (zero padded): the
+    token-contiguous operand of a weight-gradient GEMM.  `want_copy`: also the untransposed bf16 copy [rows, cols]
+    (cols % 8 == 0) from the same pass.  Returns xT or (xT, copy)."""
+    lib = _lib.load()
+    if not (x.is_cuda and x.is_contiguous() and x.dim() == 2 and x.dtype in (torch.float32, torch.bfloat16)):
+        raise ValueError("transpose_bf16: contiguous 2-D float32 / bfloat16 CUDA tensor")
+    rows, cols = x.shape
+    if cols % 4:
+        raise ValueError("transpose_bf16: cols must be a multiple of 4")
+    ld = (rows + 7) // 8 * 8
+    yT = torch.empty((cols, ld), dtype=torch.bfloat16, device=x.device)
+    copy = None
+    if want_copy:
+        if cols % 8:
+            raise ValueError("transpose_bf16: the bf16 copy feeds a GEMM as A: cols must be a multiple of 8")
+        copy = torch.empty((rows, cols), dtype=torch.bfloat16, device=x.device)
+    _lib.check(lib.dclip_transpose_to_bf16(x.data_ptr(), int(x.dtype == torch.bfloat16), yT.data_ptr(), _ptr(copy), rows,
+                                           cols, cols, ld, cols, _stream()), "transpose_to_bf16")
+    return (yT, copy) if want_copy else yT
+
+
+def rowsum_bf16(x: torch.Tensor, n: Optional[int] = None) -> torch.Tensor:
+    """Row sums (fp32) of the first n columns of a bf16 matrix [R, ld]."""
+    lib = _lib.load()
+    _bf16(x, "x")
+    R, ld = x.shape
+    n = ld if n is None else n
+    out = torch.empty((R,), dtype=torch.float32, device=x.device)
+    _lib.check(lib.dclip_rowsum_bf16(x.data_ptr(), out.data_ptr(), R, n, ld, _stream()), "rowsum_bf16")
+    return out
 
 
 def attention_fwd_bf16(qkv: torch.Tensor, B: int, S: int, H: int, causal: bool) -> torch.Tensor:
@@ -611,8 +652,11 @@ def attention_fwd_bf16(qkv: torch.Tensor, B: int, S: int, H: int, causal: bool) 
 
 def gemm_bf16(a: torch.Tensor, w: torch.Tensor, *, n: Optional[int] = None, k: Optional[int] = None,
               bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None, gelu: bool = False,
-              out_bf16: bool = False) -> torch.Tensor:
-    """y = epilogue(a @ w^T): a [M, lda>=K] and w [N, ldw>=K] bf16 (K-major), fp32 accumulation; y fp32 or bf16."""
+              out_bf16: bool = False, save_preact: bool = False, dgelu_of: Optional[torch.Tensor] = None,
+              out: Optional[torch.Tensor] = None):
+    """y = epilogue(a @ w^T): a [M, lda>=K] and w [N, ldw>=K] bf16 (K-major), fp32 accumulation; y fp32 or bf16.
+    Training path: `save_preact` (with gelu) also returns the bf16 pre-activation -> (y, h); `dgelu_of=h` multiplies the
+    result by quick_gelu'(h)."""
     lib = _lib.load()
     _bf16(a, "a"), _bf16(w, "w")
     M, lda = a.shape
@@ -631,10 +675,28 @@ def gemm_bf16(a: torch.Tensor, w: torch.Tensor, *, n: Optional[int] = None, k: O
         epi |= EPI_RESIDUAL
         if tuple(_f32(residual, "residual").shape) != (M, N):
             raise ValueError("gemm_bf16: residual shape")
-    out = torch.empty((M, N), dtype=torch.bfloat16 if out_bf16 else torch.float32, device=a.device)
-    _lib.check(lib.dclip_gemm_bf16(a.data_ptr(), w.data_ptr(), out.data_ptr(), _ptr(bias), _ptr(residual), M, N, K, lda,
-                                   ldw, N, epi, int(out_bf16), _stream()), "gemm_bf16")
-    return out
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.bfloat16 if out_bf16 else torch.float32, device=a.device)
+    elif tuple(out.shape) != (M, N) or out.dtype != (torch.bfloat16 if out_bf16 else torch.float32) or not out.is_contiguous():
+        raise ValueError("gemm_bf16: out shape / dtype")
+    aux = None
+    if save_preact:
+        if not gelu:
+            raise ValueError("gemm_bf16: save_preact goes with gelu")
+        aux = torch.empty((M, N), dtype=torch.bfloat16, device=a.device)
+    if dgelu_of is not None:
+        if gelu or tuple(_bf16(dgelu_of, "dgelu_of").shape) != (M, N):
+            raise ValueError("gemm_bf16: dgelu_of must be the [M, N] bf16 pre-activation (and excludes gelu)")
+        epi |= EPI_DGELU
+        aux = dgelu_of
+    if aux is None:
+        _lib.check(lib.dclip_gemm_bf16(a.data_ptr(), w.data_ptr(), out.data_ptr(), _ptr(bias), _ptr(residual), M, N, K, lda,
+                                       ldw, N, epi, int(out_bf16), _stream()), "gemm_bf16")
+    else:
+        _lib.check(lib.dclip_gemm_bf16_ex(a.data_ptr(), w.data_ptr(), out.data_ptr(), _ptr(bias), _ptr(residual),
+                                          aux.data_ptr(), M, N, K, lda, ldw, N, epi, int(out_bf16), _stream()),
+                   "gemm_bf16_ex")
+    return (out, aux) if save_preact else out
 
 
 # ------------------------------------------------------------------------------------------- crop front end

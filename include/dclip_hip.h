@@ -281,6 +281,25 @@ int dclip_clip_preprocess_u8(const uint8_t* images, const int32_t* dims, float* 
 int dclip_gemm_bf16(const void* A, const void* W, void* C, const float* bias, const float* residual, int M, int N,
                     int K, int lda, int ldw, int ldc, int epilogue, int out_bf16, void* stream);
 int dclip_cast_f32_bf16(const float* x, void* y, int rows, int cols, int ldx, int ldy, void* stream);
+/* bf16 TRAINING path (the student of configs c3 / c5; opt-in `student_precision="bf16"`, the default and the benched
+ * config c2 stay exact fp32).  Forward, dgrad and wgrad GEMMs of the trainable vision tower — the autograd of
+ * `self.student.get_image_features(...)` (training/CLIP_image_distillation.py:601) — run through dclip_gemm_bf16 with fp32
+ * accumulation and fp32 master weights; residual stream, LayerNorm, softmax and the attention core stay fp32.
+ *   gemm_bf16_ex         dclip_gemm_bf16 + `aux` (bf16 [M][ldc]): with GELU the pre-activation (bias included) is stored
+ *                        there and the activation is taken of the STORED value; with DGELU (no GELU) the result is
+ *                        multiplied by quick_gelu'(aux).
+ *   layernorm_fwd_bf16_stats   layernorm_fwd_bf16 that also returns mean / rstd (fp32 [rows]) for the backward.
+ *   transpose_to_bf16    x [rows][cols] (fp32, or bf16 when x_is_bf16) -> yT [cols][ldyT] bf16 (ldyT >= rows, multiple
+ *                        of 8, zero padded) and, if y_copy != NULL, the untransposed bf16 copy [rows][ldy]: the
+ *                        token-contiguous operands of dW = (dY^T)(X^T)^T and the A operand of the dgrad GEMM.
+ *   rowsum_bf16          out[r] = sum of row r of a bf16 matrix [R][ld] (a bias gradient from dY^T). */
+int dclip_gemm_bf16_ex(const void* A, const void* W, void* C, const float* bias, const float* residual, void* aux, int M,
+                       int N, int K, int lda, int ldw, int ldc, int epilogue, int out_bf16, void* stream);
+int dclip_layernorm_fwd_bf16_stats(const float* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                                   int rows, int D, float eps, void* stream);
+int dclip_transpose_to_bf16(const void* x, int x_is_bf16, void* yT, void* y_copy, int rows, int cols, int ldx, int ldyT,
+                            int ldy, void* stream);
+int dclip_rowsum_bf16(const void* x, float* out, int R, int n, int ld, void* stream);
 /* Softmax attention of the frozen towers on bf16 q/k/v (the fused projection [B*S, 3*H*64] as written by
  * dclip_gemm_bf16 with out_bf16): fp32 scores / softmax, bf16 P and context [B*S, H*64].  Forward only. */
 int dclip_attention_fwd_bf16(const void* qkv, void* out, int B, int S, int H, int causal, void* stream);

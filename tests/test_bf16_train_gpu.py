@@ -1,0 +1,152 @@
+"""bf16 TRAINING path of the student's vision tower (BASELINE configs c3 / c5 quote the step in bf16): helper kernels
+against exact references, and the step's loss / gradients against the fp32 path and the fp32 CPU oracle.  bf16 has an
+8-bit mantissa: the gate is the loss (1e-3 relative vs the fp32 oracle at real model size) — embedding and gradient
+errors are MEASURED and reported, with loose sanity bounds."""
+import argparse
+
+import pytest
+import torch
+
+from dclip_amd import config as dcfg, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def rnd(shape, seed, scale=1.0):
+    return torch.randn(shape, generator=torch.Generator().manual_seed(seed)) * scale
+
+
+@pytest.mark.parametrize("rows,cols", [(64, 64), (85, 132), (12800, 768), (100, 3072), (7, 8), (513, 260)])
+@pytest.mark.parametrize("src", ["f32", "bf16"])
+def test_transpose_to_bf16(rows, cols, src):
+    from dclip_amd import ops
+    dev = torch.device("cuda:0")
+    x = rnd((rows, cols), rows + cols)
+    xin = x.to(dev) if src == "f32" else x.to(torch.bfloat16).to(dev)
+    want = x.to(torch.bfloat16)
+    if cols % 8 == 0:
+        yT, copy = ops.transpose_bf16(xin, want_copy=True)
+        assert torch.equal(copy.cpu(), want)
+    else:
+        yT = ops.transpose_bf16(xin)
+    ld = (rows + 7) // 8 * 8
+    assert tuple(yT.shape) == (cols, ld)
+    assert torch.equal(yT[:, :rows].cpu(), want.t())
+    if ld > rows:
+        assert float(yT[:, rows:].float().abs().sum()) == 0.0            # zero padded: safe as a GEMM operand tail
+
+
+def test_rowsum_bf16_and_ln_stats():
+    from dclip_amd import ops
+    dev = torch.device("cuda:0")
+    x = rnd((300, 1288), 5).to(torch.bfloat16)
+    got = ops.rowsum_bf16(x.to(dev), 1283).cpu()
+    want = x[:, :1283].double().sum(1)
+    assert float((got.double() - want).abs().max()) < 1e-3 * float(want.abs().max() + 1)
+    h, g, b = rnd((33, 768), 1, 2.0), 1 + rnd((768,), 2, 0.1), rnd((768,), 3, 0.1)
+    y, mean, rstd = ops.layernorm_fwd_bf16(h.to(dev), g.to(dev), b.to(dev), 1e-5, save_stats=True)
+    y0, mean0, rstd0 = ops.layernorm_fwd(h.to(dev), g.to(dev), b.to(dev), 1e-5)
+    assert torch.allclose(mean, mean0, rtol=1e-6, atol=1e-6) and torch.allclose(rstd, rstd0, rtol=1e-6, atol=1e-6)
+    assert torch.equal(y, ops.layernorm_fwd_bf16(h.to(dev), g.to(dev), b.to(dev), 1e-5))
+
+
+@pytest.mark.parametrize("M,N,K", [(400, 768, 768), (12800, 3072, 768), (13, 64, 72)])
+def test_gemm_bf16_preact_and_dgelu(M, N, K):
+    from dclip_amd import ops
+    dev = torch.device("cuda:0")
+    a, w, bias = rnd((M, K), 1), rnd((N, K), 2, 0.1), rnd((N,), 3)
+    a16, w16 = ops.cast_bf16(a.to(dev)), ops.cast_bf16(w.to(dev))
+    pre = a.to(torch.bfloat16).double() @ w.to(torch.bfloat16).double().t() + bias.double()
+    g16, h16 = ops.gemm_bf16(a16, w16, k=K, bias=bias.to(dev), gelu=True, out_bf16=True, save_preact=True)
+    assert float((h16.cpu().double() - pre).abs().max() / pre.abs().max()) < 5e-3            # one bf16 rounding
+    hs = h16.cpu().double()
+    ref_g = hs * torch.sigmoid(1.702 * hs)                                                     # activation OF THE SAVED value
+    assert float((g16.cpu().double() - ref_g).abs().max() / ref_g.abs().max()) < 5e-3
+    # dgelu: (dy @ w2^T) * gelu'(h)
+    dy, w2 = rnd((M, K), 7), rnd((N, K), 8, 0.1)
+    dy16, w2_16 = ops.cast_bf16(dy.to(dev)), ops.cast_bf16(w2.to(dev))
+    got = ops.gemm_bf16(dy16, w2_16, k=K, dgelu_of=h16).cpu().double()
+    s = torch.sigmoid(1.702 * hs)
+    want = (dy.to(torch.bfloat16).double() @ w2.to(torch.bfloat16).double().t()) * (s * (1 + 1.702 * hs * (1 - s)))
+    assert float((got - want).abs().max() / want.abs().max()) < 1e-5 * max(1.0, K ** 0.5)
+
+
+def _named_grads(model):
+    return {n: p.grad.detach().double().cpu().reshape(-1) for n, p in model.named_parameters() if p.grad is not None}
+
+
+def _step(model, pix, ids, t_img, precision):
+    from dclip_amd import functional
+    for p in model.parameters():
+        p.grad = None
+    img = model.get_image_features(pixel_values=pix, precision=precision)
+    with torch.no_grad():
+        txt = model.get_text_features(input_ids=ids)
+    loss = functional.cosine_distillation_loss(img, t_img) + functional.contrastive_loss(img, txt)
+    loss.backward()
+    return float(loss.detach()), img.detach().clone(), _named_grads(model)
+
+
+@pytest.mark.parametrize("name,mk,B", [("tiny", dcfg.tiny, 6), ("ViT-B/32", dcfg.vit_b32, 8)])
+def test_bf16_training_step_against_fp32(name, mk, B):
+    """Same weights, same batch: the bf16-GEMM step vs the exact fp32 step of the same library (which the c1 / c2
+    goldens pin to the reference)."""
+    from dclip_amd.clip_model import from_hf_state_dict
+    dev = torch.device("cuda:0")
+    cfg = mk()
+    m = from_hf_state_dict(cfg, synth.synth_clip_state_dict(cfg, seed=0, gain=3.0), device=dev)
+    for p in m.text_model.parameters():
+        p.requires_grad = False
+    m.text_projection.weight.requires_grad = False
+    m.logit_scale.requires_grad = False
+    pix = synth.synth_pixel_values(B, cfg.vision, seed=0).to(dev)
+    ids = synth.synth_input_ids(B, cfg.text, seed=3, ragged=True).to(dev)
+    t_img = synth.synth_embeddings(B, cfg.projection_dim, seed=1).to(dev)
+    l32, e32, g32 = _step(m, pix, ids, t_img, "fp32")
+    l16, e16, g16 = _step(m, pix, ids, t_img, "bf16")
+    l16b, _, g16b = _step(m, pix, ids, t_img, "bf16")
+    assert l16 == l16b and all(torch.equal(g16[k], g16b[k]) for k in g16)          # deterministic
+    assert set(g16) == set(g32)
+    cos = {k: float(g16[k] @ g32[k] / (g16[k].norm() * g32[k].norm()).clamp_min(1e-30)) for k in g32}
+    nrm = {k: float(g16[k].norm() / g32[k].norm().clamp_min(1e-30)) for k in g32}
+    worst = sorted(cos.items(), key=lambda kv: kv[1])[:3]
+    emb_rel = float((e16 - e32).abs().max() / e32.abs().max())
+    emb_cos = float(torch.nn.functional.cosine_similarity(e16, e32, dim=1).min())
+    print(f"[{name}] loss fp32 {l32:.6f} bf16 {l16:.6f} (rel {abs(l16 - l32) / abs(l32):.2e}); embedding max rel {emb_rel:.2e}, "
+          f"min cos {emb_cos:.6f}; grad cosine min {min(cos.values()):.5f} median {sorted(cos.values())[len(cos) // 2]:.5f}; "
+          f"grad norm ratio {min(nrm.values()):.3f}..{max(nrm.values()):.3f}; worst {worst}")
+    assert abs(l16 - l32) <= 2e-3 * abs(l32)
+    assert emb_cos > 0.999
+    assert min(cos.values()) > 0.98 and 0.9 < min(nrm.values()) and max(nrm.values()) < 1.1
+
+
+def test_bf16_student_c3_step_loss_vs_oracle():
+    """The gate for the bf16 configs: one c3-shaped step (ViT-B/32 student in bf16, teacher embedding given) — loss within
+    1e-3 relative of the fp32 CPU oracle; the optimizer then moves the fp32 master weights and the bf16 copies follow."""
+    from dclip_amd.clip_model import from_hf_state_dict
+    from dclip_amd.CLIP_image_distillation import CLIPImageDistillation
+    from dclip_amd.optim import FusedAdamW
+    from oracle import dclip_oracle as O
+    dev = torch.device("cuda:0")
+    cfg = dcfg.vit_b32()
+    sd = synth.synth_clip_state_dict(cfg, seed=0, gain=3.0)
+    student = from_hf_state_dict(cfg, sd, device=dev)
+    hp = argparse.Namespace(learning_rate=1e-4, warmup_steps=0, total_steps=10, train_batch_size=4, eval_batch_size=4)
+    mod = CLIPImageDistillation(hp, student, None, freeze_mode="north_star", student_precision="bf16").to(dev)
+    B = 4
+    pix = synth.synth_pixel_values(B, cfg.vision, seed=0)
+    ids = synth.synth_input_ids(B, cfg.text, seed=3, ragged=True, min_len=8)
+    t_img = synth.synth_embeddings(B, cfg.projection_dim, seed=1)
+    batch = {"pixel_values": pix.to(dev), "input_ids": ids.to(dev), "teacher_image_emb": t_img.to(dev)}
+    loss = mod.training_step(batch)
+    loss.backward()
+    with torch.no_grad():
+        ref = O.distill_step(sd, cfg, pix, ids, t_img)
+    got, want = float(loss.detach()), float(ref["loss"])
+    print(f"c3-shaped bf16 student step: loss {got:.6f} vs fp32 oracle {want:.6f} (rel {abs(got - want) / abs(want):.2e})")
+    assert abs(got - want) <= 1e-3 * abs(want)
+    opt = FusedAdamW([p for p in mod.parameters() if p.requires_grad], lr=1e-3, max_grad_norm=0.5)
+    opt.step()
+    opt.zero_grad(set_to_none=True)
+    loss2 = mod.training_step(batch)
+    assert float(loss2.detach()) < got            # the update was seen by the bf16 weight copies (version-keyed cache)
