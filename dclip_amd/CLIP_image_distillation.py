@@ -209,8 +209,14 @@ class CLIPImageDistillation(LightningLikeModule):
             # embeddings; the sentence embedding is row first-EOS of that pass.  One text forward serves the teacher's
             # tokens, the teacher's sentence target and the (frozen) student text features.
             shared_sentence = self.teacher.last_sentence_embedding
-        student_text = (shared_sentence if shared_sentence is not None
-                        else self.student.get_text_features(input_ids=tokens)).float()
+        if shared_sentence is not None:
+            student_text = shared_sentence.float()
+        elif self.student_precision == "bf16" and not any(p.requires_grad for p in self.student.text_model.parameters()) \
+                and not self.student.text_projection.weight.requires_grad:
+            with torch.no_grad():          # frozen text tower of a bf16 student: bf16 GEMM inputs there as well
+                student_text = self.student.get_text_features(input_ids=tokens, precision="bf16").float()
+        else:
+            student_text = self.student.get_text_features(input_ids=tokens).float()
         if teacher_text is None:
             with torch.no_grad():
                 if self.teacher.shares_text_tower_with(self.student):

@@ -72,6 +72,9 @@ SIGNATURES = {
     "dclip_layernorm_fwd_bf16_stats": (I, [P, P, P, P, P, P, I, I, F, P]),
     "dclip_transpose_to_bf16": (I, [P, I, P, P, I, I, I, I, I, P]),
     "dclip_rowsum_bf16": (I, [P, P, I, I, I, P]),
+    "dclip_gemm_bf16_splitk_plan": (I, [I, I, I]),
+    "dclip_gemm_bf16_splitk_workspace": (Z, [I, I, I]),
+    "dclip_gemm_bf16_splitk": (I, [P, P, P, I, I, I, I, I, I, I, P, Z, P]),
     "dclip_sumsq_blocks": (I, [Z]),
     "dclip_sumsq_f32": (I, [P, Z, P, P]),
     "dclip_clip_coef": (I, [P, I, F, P, P, P]),

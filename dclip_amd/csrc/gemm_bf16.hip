@@ -30,6 +30,8 @@ struct GemmBf16Params {
   int out_bf16;
   int tiles_m, tiles_n;
   unsigned short* aux;   // bf16 [M][ldc]: GELU writes the pre-activation there, DGELU reads it (training path)
+  int k_per_split;       // split-K (gridDim.y > 1): multiple of 64; 0 = whole K
+  float* slab;           // split-K partials [split][M][N] fp32 (raw accumulators), or nullptr
 };
 
 // 4 consecutive bf16 at p (8-byte aligned) -> 4 floats
@@ -76,12 +78,18 @@ __global__ void __launch_bounds__(256, 2) gemm_bf16_kernel(GemmBf16Params p) {
   const int gsize = min(GROUP_M, p.tiles_m - first_m);
   const int tile_m = first_m + (swz % per_group) % gsize, tile_n = (swz % per_group) / gsize;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
-  const int nk = (p.K + BKH - 1) / BKH;
+  const int kbeg = p.k_per_split ? blockIdx.y * p.k_per_split : 0;
+  const int kspan = (p.k_per_split ? min(p.K, kbeg + p.k_per_split) : p.K) - kbeg;   // this work item's share of K
+  const int nk = (kspan + BKH - 1) / BKH;
 
-  const __bf16* a_org = p.A + (size_t)m0 * p.lda;
-  const __bf16* w_org = p.W + (size_t)n0 * p.ldw;
+  const __bf16* a_org = p.A + (size_t)m0 * p.lda + kbeg;
+  const __bf16* w_org = p.W + (size_t)n0 * p.ldw + kbeg;
   const int a_rows = min(BM, p.M - m0), w_rows = min(BN, p.N - n0);
-  const size_t a_bytes = ((size_t)(a_rows - 1) * p.lda + p.K) * 2, w_bytes = ((size_t)(w_rows - 1) * p.ldw + p.K) * 2;
+  // Range checking is per DWORD: with an odd K the last valid element of the LAST row shares its dword with element K,
+  // which must therefore be inside the descriptor too (it is inside the allocation: lda, ldw are multiples of 8 and
+  // >= K; mask_chunk zeroes it).
+  const size_t a_bytes = (((size_t)(a_rows - 1) * p.lda + (p.K - kbeg)) * 2 + 3) & ~(size_t)3,
+               w_bytes = (((size_t)(w_rows - 1) * p.ldw + (p.K - kbeg)) * 2 + 3) & ~(size_t)3;
   const __amdgpu_buffer_rsrc_t a_rsrc =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a_org), 0, (int)min(a_bytes, (size_t)0x7fffffff), 0x00020000);
   const __amdgpu_buffer_rsrc_t w_rsrc =
@@ -182,11 +190,11 @@ __global__ void __launch_bounds__(256, 2) gemm_bf16_kernel(GemmBf16Params p) {
 
   load_tile(0);
 #pragma unroll
-  for (int c = 0; c < A_CHUNKS + B_CHUNKS; ++c) store_chunk(0, c, p.K);
+  for (int c = 0; c < A_CHUNKS + B_CHUNKS; ++c) store_chunk(0, c, kspan);
   __syncthreads();
   for (int kt = 0; kt < nk; ++kt) {
     const bool stage = kt + 1 < nk;
-    compute(kt & 1, kt, stage, p.K - (kt + 1) * BKH);
+    compute(kt & 1, kt, stage, kspan - (kt + 1) * BKH);
     __syncthreads();
   }
 
@@ -209,6 +217,10 @@ __global__ void __launch_bounds__(256, 2) gemm_bf16_kernel(GemmBf16Params p) {
     const int row = m0 + lr, col = n0 + lc;
     if (row >= p.M || col >= p.N) continue;  // N % 4 == 0: a chunk is inside or outside as a whole
     f32x4 v = *reinterpret_cast<const f32x4*>(ct + lr * BN + lc);
+    if (p.slab) {   // split-K partial: raw accumulators, the reduce kernel finishes
+      *reinterpret_cast<f32x4*>(p.slab + ((size_t)blockIdx.y * p.M + row) * p.N + col) = v;
+      continue;
+    }
     if (p.epilogue & DCLIP_EPI_BIAS) v += *reinterpret_cast<const f32x4*>(p.bias + col);
     const size_t off = (size_t)row * p.ldc + col;
     if (p.epilogue & DCLIP_EPI_GELU) {
@@ -493,6 +505,18 @@ __global__ void __launch_bounds__(256) ln_fwd_bf16_kernel(const float* __restric
   }
 }
 
+// C[M][ldc] = sum over splits of slab[s][M][N], in fixed order (deterministic); one float4 per thread
+__global__ void __launch_bounds__(256) splitk_reduce_bf16_kernel(const float* __restrict__ slab, float* __restrict__ C, int M,
+                                                                 int N, int ldc, int splits) {
+  const size_t total4 = (size_t)M * N / 4;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
+    f32x4 s = *reinterpret_cast<const f32x4*>(slab + i * 4);
+    for (int z = 1; z < splits; ++z) s += *reinterpret_cast<const f32x4*>(slab + (size_t)z * M * N + i * 4);
+    const size_t row = (i * 4) / N, col = (i * 4) % N;
+    *reinterpret_cast<f32x4*>(C + row * ldc + col) = s;
+  }
+}
+
 inline int grid_for(size_t work) {
   size_t b = (work + 255) / 256;
   return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
@@ -526,7 +550,7 @@ DCLIP_API int dclip_gemm_bf16_ex(const void* A, const void* W, void* C, const fl
   static const int big_min = getenv("DCLIP_BF16_BIG_MIN") ? atoi(getenv("DCLIP_BF16_BIG_MIN")) : 128;   // tuning aid
   if (K % BKH == 0 && (long)cdiv(M, 256) * cdiv(N, 256) >= big_min) {
     GemmBf16Params pb{(const __bf16*)A, (const __bf16*)W, C, bias, residual, M, N, K, lda, ldw, ldc, epilogue, out_bf16, 0, 0,
-                      (unsigned short*)aux};
+                      (unsigned short*)aux, 0, nullptr};
     launch_dma<256, 256, 2, 4>(pb, st);
     DCLIP_CHECK_LAUNCH("gemm_bf16.dma");
     return DCLIP_OK;
@@ -534,7 +558,7 @@ DCLIP_API int dclip_gemm_bf16_ex(const void* A, const void* W, void* C, const fl
   const bool small = (long)cdiv(M, 128) * cdiv(N, 128) < 256;  // fewer tiles than CUs: use the finer tile
   const int bm = small ? 64 : 128, bn = bm;
   GemmBf16Params p{(const __bf16*)A, (const __bf16*)W, C, bias, residual, M, N, K, lda, ldw, ldc, epilogue, out_bf16,
-                   cdiv(M, bm), cdiv(N, bn), (unsigned short*)aux};
+                   cdiv(M, bm), cdiv(N, bn), (unsigned short*)aux, 0, nullptr};
   const size_t lds = (size_t)2 * (bm + bn) * BKH * 2;
   if (small) hipLaunchKernelGGL((gemm_bf16_kernel<64, 64>), dim3(p.tiles_m * p.tiles_n), dim3(256), lds, st, p);
   else hipLaunchKernelGGL((gemm_bf16_kernel<128, 128>), dim3(p.tiles_m * p.tiles_n), dim3(256), lds, st, p);
@@ -574,5 +598,50 @@ DCLIP_API int dclip_layernorm_fwd_bf16_stats(const float* x, const float* gamma,
   else LN16(8);
 #undef LN16
   DCLIP_CHECK_LAUNCH("layernorm_fwd_bf16");
+  return DCLIP_OK;
+}
+
+// Split-K form for products with few output tiles and a long contraction — the weight gradients of the bf16 training
+// path, dW[out,in] = (dY^T)[out,tok] (X^T)[in,tok]^T with tok = batch x sequence (12,800 .. 25,600): `splits` work items
+// per 128x128 tile write fp32 partials to the caller's workspace, a second kernel sums them in fixed order.  fp32 C, no
+// epilogue.  dclip_gemm_bf16_splitk_plan returns the split count this library would choose (1 = use dclip_gemm_bf16).
+DCLIP_API int dclip_gemm_bf16_splitk_plan(int M, int N, int K) {
+  const long tiles = (long)cdiv(M, 128) * cdiv(N, 128);
+  if (tiles >= 192 || K < 2048) return 1;
+  int s = (int)((768 + tiles - 1) / tiles);                 // ~3 work items per CU
+  const int kmax = K / 512;                                  // at least 8 K-tiles per work item
+  s = s > kmax ? kmax : s;
+  return s < 2 ? 1 : (s > 64 ? 64 : s);
+}
+
+DCLIP_API size_t dclip_gemm_bf16_splitk_workspace(int M, int N, int splits) {
+  return splits > 1 ? (size_t)splits * M * N * sizeof(float) : 0;
+}
+
+DCLIP_API int dclip_gemm_bf16_splitk(const void* A, const void* W, float* C, int M, int N, int K, int lda, int ldw, int ldc,
+                                     int splits, void* workspace, size_t workspace_bytes, void* stream) {
+  DCLIP_REQUIRE(A && W && C, "gemm_bf16_splitk: null operand");
+  DCLIP_REQUIRE(M > 0 && N > 0 && K > 0 && splits >= 1 && splits <= 1024, "gemm_bf16_splitk: bad shape");
+  DCLIP_REQUIRE(lda % 8 == 0 && ldw % 8 == 0 && lda >= K && ldw >= K, "gemm_bf16_splitk: lda/ldw must be multiples of 8 and >= K");
+  DCLIP_REQUIRE(N % 4 == 0 && ldc % 4 == 0 && ldc >= N, "gemm_bf16_splitk: N / ldc must be multiples of 4");
+  DCLIP_REQUIRE(((uintptr_t)A | (uintptr_t)W | (uintptr_t)C) % 16 == 0, "gemm_bf16_splitk: operands must be 16-byte aligned");
+  if (splits == 1) return dclip_gemm_bf16_ex(A, W, C, nullptr, nullptr, nullptr, M, N, K, lda, ldw, ldc, 0, 0, stream);
+  const int kps = cdiv(cdiv(K, splits), BKH) * BKH;
+  const int s_eff = cdiv(K, kps);
+  const size_t need = (size_t)s_eff * M * N * sizeof(float);
+  if (!workspace || workspace_bytes < need) {
+    dclip_set_error("gemm_bf16_splitk: needs %zu workspace bytes, got %zu", need, workspace_bytes);
+    return DCLIP_EWORKSPACE;
+  }
+  DCLIP_REQUIRE((uintptr_t)workspace % 16 == 0, "gemm_bf16_splitk: workspace must be 16-byte aligned");
+  GemmBf16Params p{(const __bf16*)A, (const __bf16*)W, C, nullptr, nullptr, M, N, K, lda, ldw, ldc, 0, 0,
+                   cdiv(M, 128), cdiv(N, 128), nullptr, kps, (float*)workspace};
+  hipStream_t st = (hipStream_t)stream;
+  const size_t lds = (size_t)2 * (128 + 128) * BKH * 2;
+  hipLaunchKernelGGL((gemm_bf16_kernel<128, 128>), dim3(p.tiles_m * p.tiles_n, s_eff), dim3(256), lds, st, p);
+  DCLIP_CHECK_LAUNCH("gemm_bf16_splitk");
+  hipLaunchKernelGGL(splitk_reduce_bf16_kernel, dim3(grid_for((size_t)M * N / 4)), dim3(256), 0, st, (const float*)workspace, C,
+                     M, N, ldc, s_eff);
+  DCLIP_CHECK_LAUNCH("gemm_bf16_splitk.reduce");
   return DCLIP_OK;
 }

@@ -354,7 +354,7 @@ def layer_fwd_bf16_train(x, p: LayerParams, c: dict, pre: str, B: int, S: int, H
 
 def _wgrad_bf16(dyT, xT, M: int, need_w: bool):
     """dW [out, in] fp32 = dY^T X from the token-contiguous bf16 operands dY^T [out, ld], X^T [in, ld]."""
-    return ops.gemm_bf16(dyT, xT, k=M) if need_w else None
+    return ops.gemm_bf16_wgrad(dyT, xT, M) if need_w else None
 
 
 def layer_bwd_bf16(dx2, p: LayerParams, c: dict, pre: str, saved, B: int, S: int, H: int, causal: bool, need: Dict[str, bool]):

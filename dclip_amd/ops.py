@@ -699,6 +699,23 @@ def gemm_bf16(a: torch.Tensor, w: torch.Tensor, *, n: Optional[int] = None, k: O
     return (out, aux) if save_preact else out
 
 
+def gemm_bf16_wgrad(a: torch.Tensor, w: torch.Tensor, k: int, splits: Optional[int] = None) -> torch.Tensor:
+    """dW [M, N] fp32 = a[:, :k] @ w[:, :k]^T over bf16 token-contiguous operands (a = dY^T [M, ld], w = X^T [N, ld]):
+    split-K when the output has few tiles (deterministic: partials summed in fixed order)."""
+    lib = _lib.load()
+    _bf16(a, "a"), _bf16(w, "w")
+    M, lda = a.shape
+    N, ldw = w.shape
+    if splits is None:
+        splits = lib.dclip_gemm_bf16_splitk_plan(M, N, k)
+    out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    nbytes = lib.dclip_gemm_bf16_splitk_workspace(M, N, splits)
+    ws = _ws.get(nbytes, a.device)
+    _lib.check(lib.dclip_gemm_bf16_splitk(a.data_ptr(), w.data_ptr(), out.data_ptr(), M, N, k, lda, ldw, N, splits,
+                                          _ptr(ws), nbytes, _stream()), "gemm_bf16_splitk")
+    return out
+
+
 # ------------------------------------------------------------------------------------------- crop front end
 
 def crop_resize(images_u8: torch.Tensor, dims: torch.Tensor, boxes: torch.Tensor, size: int,

@@ -300,6 +300,14 @@ int dclip_layernorm_fwd_bf16_stats(const float* x, const float* gamma, const flo
 int dclip_transpose_to_bf16(const void* x, int x_is_bf16, void* yT, void* y_copy, int rows, int cols, int ldx, int ldyT,
                             int ldy, void* stream);
 int dclip_rowsum_bf16(const void* x, float* out, int R, int n, int ld, void* stream);
+/* Split-K bf16 GEMM for the weight gradients (few output tiles, contraction over all tokens): fp32 C [M][ldc], no
+ * epilogue; `splits` K-slices per 128x128 tile write fp32 partials into the caller's workspace
+ * (dclip_gemm_bf16_splitk_workspace bytes), a second kernel adds them in fixed order (deterministic).
+ * dclip_gemm_bf16_splitk_plan(M, N, K) = the split count to pass (1: few enough tiles already). */
+int dclip_gemm_bf16_splitk_plan(int M, int N, int K);
+size_t dclip_gemm_bf16_splitk_workspace(int M, int N, int splits);
+int dclip_gemm_bf16_splitk(const void* A, const void* W, float* C, int M, int N, int K, int lda, int ldw, int ldc,
+                           int splits, void* workspace, size_t workspace_bytes, void* stream);
 /* Softmax attention of the frozen towers on bf16 q/k/v (the fused projection [B*S, 3*H*64] as written by
  * dclip_gemm_bf16 with out_bf16): fp32 scores / softmax, bf16 P and context [B*S, H*64].  Forward only. */
 int dclip_attention_fwd_bf16(const void* qkv, void* out, int B, int S, int H, int causal, void* stream);

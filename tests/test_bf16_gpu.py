@@ -12,12 +12,19 @@ def rnd(shape, seed, scale=1.0):
 
 
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (400, 768, 768), (257, 132, 588), (2048, 3072, 768), (13, 64, 72),
-                                   (12800, 768, 3072)])
+                                   (12800, 768, 3072), (128, 256, 85), (64, 64, 21), (130, 132, 149)])   # odd K too
 def test_gemm_bf16_matches_rounded_inputs(M, N, K):
     from dclip_amd import ops
     dev = torch.device("cuda:0")
     a, w, bias = rnd((M, K), 1), rnd((N, K), 2, 0.1), rnd((N,), 3)
-    a16, w16 = ops.cast_bf16(a.to(dev)), ops.cast_bf16(w.to(dev))
+    if K % 4 == 0:
+        a16, w16 = ops.cast_bf16(a.to(dev)), ops.cast_bf16(w.to(dev))
+    else:            # the cast kernel takes rows of a multiple of 4 floats: pad on the host (zero tail, ld % 8 == 0)
+        ld = (K + 7) // 8 * 8
+        a16 = torch.zeros(M, ld, dtype=torch.bfloat16)
+        w16 = torch.zeros(N, ld, dtype=torch.bfloat16)
+        a16[:, :K], w16[:, :K] = a.to(torch.bfloat16), w.to(torch.bfloat16)
+        a16, w16 = a16.to(dev), w16.to(dev)
     assert a16.shape[1] % 8 == 0 and torch.equal(a16[:, :K].cpu(), a.to(torch.bfloat16))
     if a16.shape[1] > K:
         assert float(a16[:, K:].float().abs().sum()) == 0.0

@@ -71,6 +71,20 @@ def test_gemm_bf16_preact_and_dgelu(M, N, K):
     assert float((got - want).abs().max() / want.abs().max()) < 1e-5 * max(1.0, K ** 0.5)
 
 
+@pytest.mark.parametrize("M,N,K,splits", [(768, 768, 12800, None), (768, 3072, 12800, None), (2304, 768, 12800, 7),
+                                           (128, 256, 85, None), (132, 64, 4100, 3), (768, 768, 12800, 1)])
+def test_gemm_bf16_wgrad_split_k(M, N, K, splits):
+    """dW = dY^T X on token-contiguous bf16 operands, split-K with a fixed-order reduce (deterministic)."""
+    from dclip_amd import ops
+    dev = torch.device("cuda:0")
+    dy, x = rnd((K, M), 1), rnd((K, N), 2)
+    dyT, xT = ops.transpose_bf16(dy.to(dev)), ops.transpose_bf16(x.to(dev))
+    got = ops.gemm_bf16_wgrad(dyT, xT, K, splits)
+    want = dy.to(torch.bfloat16).double().t() @ x.to(torch.bfloat16).double()
+    assert float((got.double().cpu() - want).abs().max() / want.abs().max()) < 2e-6 * max(1.0, K ** 0.5)
+    assert torch.equal(got, ops.gemm_bf16_wgrad(dyT, xT, K, splits))
+
+
 def _named_grads(model):
     return {n: p.grad.detach().double().cpu().reshape(-1) for n, p in model.named_parameters() if p.grad is not None}
 
