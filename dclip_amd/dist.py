@@ -57,26 +57,53 @@ def global_loss_value(loss_image, loss_text, loss_contrastive_share, group) -> t
 
 class GradSync:
     """Bucketed SUM all-reduce of the trainable parameters' gradients over the data-parallel group, overlapped with
-    the backward pass.
+    the backward pass, on PERSISTENT flat fp32 buckets.
 
-    `on_grads_ready` is installed as functional's grad-ready hook: the vision tower's backward hands over each
-    layer's gradients the moment they are final (top layer first).  They are packed into a flat fp32 bucket
-    (~`bucket_mb`, one ViT-B layer = 28 MB) and the bucket's all-reduce is launched with async_op — RCCL runs it on
-    its own stream over xGMI while the compute stream keeps back-propagating the layers below.  `finish()` (after
-    `loss.backward()`) reduces whatever the hook never saw (parameters outside the hooked tower), waits for every
-    bucket and points each `param.grad` at its slice of the reduced bucket (no copy back).  Without the hook
-    installed, `reduce()` = finish() does everything after the backward (still bucketed and asynchronous among
-    buckets).  One backward per `finish()`: with gradient accumulation call it after the LAST micro-batch only and
-    without the overlap hook (the hook sees a micro-batch's gradients, not the accumulated ones)."""
+    Layout: the parameters are walked in REVERSE registration order (the order a backward produces them: heads, the
+    vision layers from the top down, the embeddings) and cut into buckets of ~`bucket_mb` (one ViT-B layer = 28 MB);
+    every parameter owns a fixed slice of a bucket that is allocated once.
+      * `grad_buffer` (installed as functional.set_grad_alloc) hands that slice to the hand-written backward, so the
+        weight-gradient GEMMs / LayerNorm and bias reductions WRITE INTO THE BUCKET — no packing copy;
+      * `on_grads_ready` (functional.set_grad_ready_hook) is called by the vision tower's backward the moment a group
+        of gradients is final (top layer first); a gradient that was not written in place is copied into its slice; when
+        the last parameter of a bucket has arrived the bucket's all-reduce is launched with async_op — RCCL moves it over
+        xGMI on its own stream while the compute stream keeps back-propagating the layers below.  It returns True: the
+        reducer owns these gradients (autograd is handed None for them — nothing is accumulated or cloned);
+      * `finish()` (after `loss.backward()`) takes whatever no hook delivered from `.grad` (parameters outside the hooked
+        tower), zero-fills slices of parameters that received no gradient, launches the remaining buckets, waits, and
+        points every delivered parameter's `.grad` at its slice of the reduced bucket.
+    Without the hooks installed, `reduce()` = finish() does everything after the backward (still bucketed and
+    asynchronous among buckets).  One backward per `finish()`: with gradient accumulation call it after the LAST
+    micro-batch only and without the overlap hooks (the hook sees a micro-batch's gradients, not the accumulated ones).
+    The buckets are reused every step: the optimizer must have consumed `.grad` before the next backward starts (same
+    stream: it has)."""
 
     def __init__(self, params: Iterable[torch.nn.Parameter], group, bucket_mb: float = 25.0):
         self.group = group
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
         self._ids = {id(p) for p in self.params}
         self.bucket_elems = max(1, int(bucket_mb * (1 << 20) / 4))
-        self._pending = []          # (param, grad) waiting for a bucket
-        self._pending_elems = 0
-        self._inflight = []         # (work, flat, [(param, offset, numel)])
+        # bucket plan: [(first param index, ...)] over the reversed parameter list; buffers allocated lazily (device of p)
+        self._slot = {}             # id(param) -> (bucket index, offset, numel)
+        self._bucket_params: List[List[torch.nn.Parameter]] = []
+        self._bucket_size: List[int] = []
+        cur, size = [], 0
+        for p in reversed(self.params):
+            n = (p.numel() + 3) // 4 * 4                       # 16-byte aligned slices (the GEMM writes C there)
+            self._slot[id(p)] = (len(self._bucket_params), size, p.numel())
+            cur.append(p)
+            size += n
+            if size >= self.bucket_elems:
+                self._bucket_params.append(cur)
+                self._bucket_size.append(size)
+                cur, size = [], 0
+        if cur:
+            self._bucket_params.append(cur)
+            self._bucket_size.append(size)
+        self._flat: List[Optional[torch.Tensor]] = [None] * len(self._bucket_params)
+        self._arrived = [0] * len(self._bucket_params)
+        self._launched = [False] * len(self._bucket_params)
+        self._work = []             # (bucket index, work)
         self._seen = set()
         self.reset_stats()
 
@@ -85,81 +112,120 @@ class GradSync:
         self._n_finish = 0
         self._n_buckets = 0
         self._n_bytes = 0
+        self._n_inplace = 0
+        self._n_copied = 0
         self._wait_events = []      # (before, after) event pairs around finish()'s waits, on the compute stream
 
     def stats(self) -> dict:
-        """Per-step averages since reset_stats(): buckets all-reduced, bytes all-reduced, and the EXPOSED all-reduce
-        time (how long the compute stream sat in finish() waiting for RCCL after the backward had ended)."""
+        """Per-step averages since reset_stats(): buckets all-reduced, bytes all-reduced, gradients written in place vs
+        copied into their slice, and the EXPOSED all-reduce time (how long the compute stream sat in finish() waiting
+        for RCCL after the backward had ended)."""
         n = max(1, self._n_finish)
         exposed = None
         if self._wait_events:
             torch.cuda.synchronize()
             exposed = sum(a.elapsed_time(b) for a, b in self._wait_events) / n
         return {"grad_buckets_per_step": self._n_buckets / n, "grad_allreduce_bytes_per_step": self._n_bytes / n,
+                "grad_tensors_written_in_place_per_step": self._n_inplace / n,
+                "grad_tensors_copied_per_step": self._n_copied / n,
                 "grad_allreduce_exposed_ms_per_step": None if exposed is None else round(exposed, 4),
                 "bucket_mb": round(self.bucket_elems * 4 / (1 << 20), 2)}
 
+    # ---- buffers
+    def _bucket(self, b: int, device) -> torch.Tensor:
+        f = self._flat[b]
+        if f is None:
+            f = torch.empty(self._bucket_size[b], dtype=torch.float32, device=device)
+            self._flat[b] = f
+        return f
+
+    def _view(self, p: torch.nn.Parameter) -> torch.Tensor:
+        b, o, n = self._slot[id(p)]
+        return self._bucket(b, p.device)[o:o + n]
+
+    def grad_buffer(self, p: torch.nn.Parameter, shape) -> Optional[torch.Tensor]:
+        """The tensor the backward should write p's gradient into (its bucket slice, viewed as `shape`), or None."""
+        if self.group is None or id(p) not in self._ids:
+            return None
+        numel = 1
+        for d in shape:
+            numel *= int(d)
+        if numel != p.numel():
+            return None
+        return self._view(p).view(tuple(shape))
+
     # ---- called during backward
-    def on_grads_ready(self, pairs):
+    def _deliver(self, p, g):
+        if id(p) in self._seen:
+            # a second delivery within one backward (a tower applied twice) would overwrite the first in the bucket
+            raise RuntimeError("GradSync: a parameter's gradient was delivered twice in one backward; use "
+                               "reduce() after the backward (no overlap hooks) for modules applied more than once")
+        self._seen.add(id(p))
+        v = self._view(p)
+        if g is None:
+            v.zero_()
+        elif g.data_ptr() == v.data_ptr():
+            self._n_inplace += 1
+        else:
+            v.copy_(g.reshape(-1))
+            self._n_copied += 1
+        b = self._slot[id(p)][0]
+        self._arrived[b] += 1
+        if self._arrived[b] == len(self._bucket_params[b]):
+            self._launch(b)
+
+    def on_grads_ready(self, pairs) -> bool:
         if self.group is None:
-            return
+            return False
         for p, g in pairs:
             if g is None or id(p) not in self._ids:
                 continue
-            if id(p) in self._seen:
-                # a second delivery within one backward (a tower applied twice) would be dropped silently and
-                # finish() would then overwrite the correctly accumulated p.grad with the first-only reduction
-                raise RuntimeError("GradSync: a parameter's gradient was delivered twice in one backward; use "
-                                   "reduce() after the backward (no overlap hook) for modules applied more than once")
-            self._seen.add(id(p))
-            self._pending.append((p, g))
-            self._pending_elems += g.numel()
-        if self._pending_elems >= self.bucket_elems:
-            self._launch()
+            self._deliver(p, g)
+        return True
 
-    def _launch(self):
-        if not self._pending:
+    def _launch(self, b: int):
+        if self._launched[b]:
             return
-        dev = self._pending[0][1].device
-        flat = torch.empty(self._pending_elems, dtype=torch.float32, device=dev)
-        layout, o = [], 0
-        for p, g in self._pending:
-            n = g.numel()
-            layout.append((p, o, n))
-            o += n
-        # ONE multi-tensor copy packs the bucket (a copy per tensor is ~150 tiny launches per step)
-        torch._foreach_copy_([flat[o:o + n] for _, o, n in layout], [g.reshape(-1) for _, g in self._pending])
+        self._launched[b] = True
+        flat = self._flat[b]
+        pad_lo = 0
+        for p in self._bucket_params[b]:                      # alignment gaps between slices carry no data: keep them finite
+            _, o, n = self._slot[id(p)]
+            if o > pad_lo:
+                flat[pad_lo:o].zero_()
+            pad_lo = o + n
+        if pad_lo < flat.numel():
+            flat[pad_lo:].zero_()
         work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-        self._inflight.append((work, flat, layout))
+        self._work.append((b, work))
         self._n_buckets += 1
         self._n_bytes += flat.numel() * 4
-        self._pending, self._pending_elems = [], 0
 
     # ---- called after backward
     def finish(self):
         if self.group is None:
             return
+        delivered = set(self._seen)
         for p in reversed(self.params):                 # whatever no hook delivered (other towers, heads)
-            if p.grad is not None and id(p) not in self._seen:
-                self._seen.add(id(p))
-                self._pending.append((p, p.grad))
-                self._pending_elems += p.grad.numel()
-                if self._pending_elems >= self.bucket_elems:
-                    self._launch()
-        self._launch()
-        timed = bool(self._inflight) and self._inflight[0][1].is_cuda
+            if id(p) not in self._seen:
+                if p.grad is not None:
+                    delivered.add(id(p))
+                self._deliver(p, p.grad)                # None: the slice is zero-filled (the other ranks may have one)
+        timed = bool(self._work) and self._flat[self._work[0][0]].is_cuda
         if timed:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        for work, flat, layout in self._inflight:
+        for _b, work in self._work:
             work.wait()
-            for p, o, n in layout:                        # zero-copy: .grad becomes a view of the reduced bucket
-                if p.grad is not None:
-                    p.grad = flat[o:o + n].view_as(p)
         if timed:
             e1.record()
             self._wait_events.append((e0, e1))
+        for p in self.params:                           # zero-copy: .grad is a view of the reduced bucket
+            if id(p) in delivered:
+                p.grad = self._view(p).view_as(p)
         self._n_finish += 1
-        self._inflight, self._seen = [], set()
+        self._work, self._seen = [], set()
+        self._arrived = [0] * len(self._bucket_params)
+        self._launched = [False] * len(self._bucket_params)
 
     reduce = finish

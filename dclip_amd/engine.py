@@ -54,41 +54,60 @@ def layer_fwd(x, p: LayerParams, B: int, S: int, H: int, causal: bool, eps: floa
     return x2, saved
 
 
-def linear_param_grads(dy, x, need_w: bool, need_b: bool, gr: Dict[str, torch.Tensor], wkey: str, bkey: str):
+def _fresh(_name: str, shape, device) -> torch.Tensor:
+    return torch.empty(shape, dtype=torch.float32, device=device)
+
+
+def _galloc(alloc, name: str, shape, device) -> torch.Tensor:
+    """Where a parameter gradient is written.  `alloc(name, shape)` (data parallel: dist.GradSync hands out the
+    parameter's slice of its persistent all-reduce bucket, so the wgrad GEMM writes straight into it) may return None."""
+    t = alloc(name, shape) if alloc is not None else None
+    return t if t is not None else _fresh(name, shape, device)
+
+
+def linear_param_grads(dy, x, need_w: bool, need_b: bool, gr: Dict[str, torch.Tensor], wkey: str, bkey: str, alloc=None):
     """dW = dy^T x and db = colsum(dy) of one nn.Linear.  When both are wanted the bias gradient comes out of the
     weight-gradient GEMM (DCLIP_EPI_A_ROWSUM): dy is streamed once, no separate column-sum launch."""
+    dev = dy.device
     if need_w and need_b:
-        gr[bkey] = torch.empty((dy.shape[1],), dtype=torch.float32, device=dy.device)
-        gr[wkey] = ops.gemm(dy, x, ops.LAYOUT_TN, a_rowsum=gr[bkey])
+        gr[bkey] = _galloc(alloc, bkey, (dy.shape[1],), dev)
+        gr[wkey] = ops.gemm(dy, x, ops.LAYOUT_TN, out=_galloc(alloc, wkey, (dy.shape[1], x.shape[1]), dev), a_rowsum=gr[bkey])
     elif need_w:
-        gr[wkey] = ops.gemm(dy, x, ops.LAYOUT_TN)
+        gr[wkey] = ops.gemm(dy, x, ops.LAYOUT_TN, out=_galloc(alloc, wkey, (dy.shape[1], x.shape[1]), dev))
     elif need_b:
-        gr[bkey] = ops.colsum(dy)
+        gr[bkey] = ops.colsum(dy, out=_galloc(alloc, bkey, (dy.shape[1],), dev))
 
 
-def layer_bwd(dx2, p: LayerParams, saved, B: int, S: int, H: int, causal: bool, need: Dict[str, bool]):
-    """Returns (dx, grads) with grads keyed like LayerParams.FIELDS (missing = not needed)."""
+def _ln_bwd(dy, x, gamma, mean, rstd, dresidual, want: bool, gr, wkey: str, bkey: str, alloc):
+    """LayerNorm backward; dγ / dβ land where `alloc` says."""
+    if want:
+        dg = _galloc(alloc, wkey, tuple(gamma.shape), dy.device)
+        db = _galloc(alloc, bkey, tuple(gamma.shape), dy.device)
+        dx, dg, db = ops.layernorm_bwd(dy, x, gamma, mean, rstd, dresidual=dresidual, dgamma=dg, dbeta=db, accumulate=False)
+        gr[wkey], gr[bkey] = dg, db
+        return dx
+    dx, _, _ = ops.layernorm_bwd(dy, x, gamma, mean, rstd, dresidual=dresidual, need_param_grads=False)
+    return dx
+
+
+def layer_bwd(dx2, p: LayerParams, saved, B: int, S: int, H: int, causal: bool, need: Dict[str, bool], alloc=None):
+    """Returns (dx, grads) with grads keyed like LayerParams.FIELDS (missing = not needed).  `alloc(field, shape)`:
+    see _galloc."""
     x, m1, r1, ln1, qkv, attn, lse, x1, m2, r2, ln2, h, g = saved
     gr: Dict[str, torch.Tensor] = {}
-    linear_param_grads(dx2, g, bool(need.get("fc2_w")), bool(need.get("fc2_b")), gr, "fc2_w", "fc2_b")
+    linear_param_grads(dx2, g, bool(need.get("fc2_w")), bool(need.get("fc2_b")), gr, "fc2_w", "fc2_b", alloc)
     dh = ops.gemm(dx2, p.fc2_w, ops.LAYOUT_NN, aux=h, epilogue=ops.EPI_DGELU)
-    linear_param_grads(dh, ln2, bool(need.get("fc1_w")), bool(need.get("fc1_b")), gr, "fc1_w", "fc1_b")
+    linear_param_grads(dh, ln2, bool(need.get("fc1_w")), bool(need.get("fc1_b")), gr, "fc1_w", "fc1_b", alloc)
     dln2 = ops.gemm(dh, p.fc1_w, ops.LAYOUT_NN)
     del dh
-    want_ln2 = bool(need.get("ln2_w") or need.get("ln2_b"))
-    dx1, dg, db = ops.layernorm_bwd(dln2, x1, p.ln2_w, m2, r2, dresidual=dx2, need_param_grads=want_ln2)
-    if want_ln2:
-        gr["ln2_w"], gr["ln2_b"] = dg, db
-    linear_param_grads(dx1, attn, bool(need.get("out_w")), bool(need.get("out_b")), gr, "out_w", "out_b")
+    dx1 = _ln_bwd(dln2, x1, p.ln2_w, m2, r2, dx2, bool(need.get("ln2_w") or need.get("ln2_b")), gr, "ln2_w", "ln2_b", alloc)
+    linear_param_grads(dx1, attn, bool(need.get("out_w")), bool(need.get("out_b")), gr, "out_w", "out_b", alloc)
     dattn = ops.gemm(dx1, p.out_w, ops.LAYOUT_NN)
     dqkv = ops.attention_bwd(qkv, attn, dattn, lse, B, S, H, causal)
-    linear_param_grads(dqkv, ln1, bool(need.get("qkv_w")), bool(need.get("qkv_b")), gr, "qkv_w", "qkv_b")
+    linear_param_grads(dqkv, ln1, bool(need.get("qkv_w")), bool(need.get("qkv_b")), gr, "qkv_w", "qkv_b", alloc)
     dln1 = ops.gemm(dqkv, p.qkv_w, ops.LAYOUT_NN)
     del dqkv
-    want_ln1 = bool(need.get("ln1_w") or need.get("ln1_b"))
-    dx, dg, db = ops.layernorm_bwd(dln1, x, p.ln1_w, m1, r1, dresidual=dx1, need_param_grads=want_ln1)
-    if want_ln1:
-        gr["ln1_w"], gr["ln1_b"] = dg, db
+    dx = _ln_bwd(dln1, x, p.ln1_w, m1, r1, dx1, bool(need.get("ln1_w") or need.get("ln1_b")), gr, "ln1_w", "ln1_b", alloc)
     return dx, gr
 
 
@@ -116,30 +135,24 @@ def last_layer_fwd_cls(x, p: LayerParams, B: int, S: int, H: int, eps: float, sa
     return x2, saved
 
 
-def last_layer_bwd_cls(dx2, p: LayerParams, saved, B: int, S: int, H: int, need: Dict[str, bool]):
+def last_layer_bwd_cls(dx2, p: LayerParams, saved, B: int, S: int, H: int, need: Dict[str, bool], alloc=None):
     """dx2 [B, D] is the gradient w.r.t. the CLS rows of the final hidden state; returns (dx [B*S, D], grads)."""
     x, m1, r1, ln1, qkv, attn, lse, x1, m2, r2, ln2, h, g = saved
     D = x.shape[1]
     gr: Dict[str, torch.Tensor] = {}
-    linear_param_grads(dx2, g, bool(need.get("fc2_w")), bool(need.get("fc2_b")), gr, "fc2_w", "fc2_b")
+    linear_param_grads(dx2, g, bool(need.get("fc2_w")), bool(need.get("fc2_b")), gr, "fc2_w", "fc2_b", alloc)
     dh = ops.gemm(dx2, p.fc2_w, ops.LAYOUT_NN, aux=h, epilogue=ops.EPI_DGELU)
-    linear_param_grads(dh, ln2, bool(need.get("fc1_w")), bool(need.get("fc1_b")), gr, "fc1_w", "fc1_b")
+    linear_param_grads(dh, ln2, bool(need.get("fc1_w")), bool(need.get("fc1_b")), gr, "fc1_w", "fc1_b", alloc)
     dln2 = ops.gemm(dh, p.fc1_w, ops.LAYOUT_NN)
-    want_ln2 = bool(need.get("ln2_w") or need.get("ln2_b"))
-    dx1, dg, db = ops.layernorm_bwd(dln2, x1, p.ln2_w, m2, r2, dresidual=dx2, need_param_grads=want_ln2)
-    if want_ln2:
-        gr["ln2_w"], gr["ln2_b"] = dg, db
-    linear_param_grads(dx1, attn, bool(need.get("out_w")), bool(need.get("out_b")), gr, "out_w", "out_b")
+    dx1 = _ln_bwd(dln2, x1, p.ln2_w, m2, r2, dx2, bool(need.get("ln2_w") or need.get("ln2_b")), gr, "ln2_w", "ln2_b", alloc)
+    linear_param_grads(dx1, attn, bool(need.get("out_w")), bool(need.get("out_b")), gr, "out_w", "out_b", alloc)
     dattn = ops.gemm(dx1, p.out_w, ops.LAYOUT_NN)
     dqkv = ops.attention_cls_bwd(qkv, attn, dattn, lse, B, S, H)          # [B*S, 3D]; d q only on the CLS rows
-    linear_param_grads(dqkv, ln1, bool(need.get("qkv_w")), bool(need.get("qkv_b")), gr, "qkv_w", "qkv_b")
+    linear_param_grads(dqkv, ln1, bool(need.get("qkv_w")), bool(need.get("qkv_b")), gr, "qkv_w", "qkv_b", alloc)
     dln1 = ops.gemm(dqkv, p.qkv_w, ops.LAYOUT_NN)
     del dqkv
-    want_ln1 = bool(need.get("ln1_w") or need.get("ln1_b"))
     dres = ops.scatter_rows(dx1, None, B, S, D)                           # the skip connection carries dx1 on CLS rows only
-    dx, dg, db = ops.layernorm_bwd(dln1, x, p.ln1_w, m1, r1, dresidual=dres, need_param_grads=want_ln1)
-    if want_ln1:
-        gr["ln1_w"], gr["ln1_b"] = dg, db
+    dx = _ln_bwd(dln1, x, p.ln1_w, m1, r1, dres, bool(need.get("ln1_w") or need.get("ln1_b")), gr, "ln1_w", "ln1_b", alloc)
     return dx, gr
 
 
@@ -213,10 +226,11 @@ def vision_fwd(p: VisionParams, pixel_values: torch.Tensor, cfg, save: bool, hid
     return out, saved
 
 
-def vision_bwd(p: VisionParams, saved, d_out: torch.Tensor, cfg, need: List[bool], on_ready=None):
+def vision_bwd(p: VisionParams, saved, d_out: torch.Tensor, cfg, need: List[bool], on_ready=None, alloc=None):
     """Gradients for VisionParams.tensors() order (None where not needed).  `on_ready(dict name -> grad)` is called as
     soon as a group of gradients is final (the tail, then each layer from the top down, then the head): the
-    data-parallel all-reduce of that group starts while the layers below are still being back-propagated."""
+    data-parallel all-reduce of that group starts while the layers below are still being back-propagated.
+    `alloc(name, shape)` may name the tensor a parameter gradient is to be written into (see _galloc)."""
     v = cfg
     cols, emb, m0, r0, saved_layers, cls_tok, mp, rp, pooled, pruned = saved
     B = cls_tok.shape[0]
@@ -224,13 +238,12 @@ def vision_bwd(p: VisionParams, saved, d_out: torch.Tensor, cfg, need: List[bool
     names = p.names()
     needd = dict(zip(names, need))
     grads: Dict[str, Optional[torch.Tensor]] = {n: None for n in names}
+    dev = d_out.device
     if needd["proj_w"]:
-        grads["proj_w"] = ops.gemm(d_out, pooled, ops.LAYOUT_TN)
+        grads["proj_w"] = ops.gemm(d_out, pooled, ops.LAYOUT_TN, out=_galloc(alloc, "proj_w", tuple(p.proj_w.shape), dev))
     dpooled = ops.gemm(d_out, p.proj_w, ops.LAYOUT_NN)
-    want = needd["post_w"] or needd["post_b"]
-    dcls, dg, db = ops.layernorm_bwd(dpooled, cls_tok, p.post_w, mp, rp, need_param_grads=want)
-    if want:
-        grads["post_w"], grads["post_b"] = dg, db
+    dcls = _ln_bwd(dpooled, cls_tok, p.post_w, mp, rp, None, bool(needd["post_w"] or needd["post_b"]), grads, "post_w", "post_b",
+                   alloc)
     if on_ready is not None:
         on_ready({n: grads[n] for n in VisionParams.TAIL if grads[n] is not None})
     n_layers = len(p.layers)
@@ -245,29 +258,30 @@ def vision_bwd(p: VisionParams, saved, d_out: torch.Tensor, cfg, need: List[bool
     dx = None if pruned else ops.scatter_rows(dcls, None, B, S, D)
     for i in range(n_layers - 1, max(lowest, 0) - 1, -1):
         lneed = {f: needd[f"layers.{i}.{f}"] for f in LayerParams.FIELDS}
+        lalloc = None if alloc is None else (lambda f, shape, i=i: alloc(f"layers.{i}.{f}", shape))
         if pruned and i == n_layers - 1:
-            dx, gr = last_layer_bwd_cls(dcls, p.layers[i], saved_layers[i], B, S, H, lneed)
+            dx, gr = last_layer_bwd_cls(dcls, p.layers[i], saved_layers[i], B, S, H, lneed, lalloc)
         else:
-            dx, gr = layer_bwd(dx, p.layers[i], saved_layers[i], B, S, H, False, lneed)
+            dx, gr = layer_bwd(dx, p.layers[i], saved_layers[i], B, S, H, False, lneed, lalloc)
         saved_layers[i] = None
         for f, t in gr.items():
             grads[f"layers.{i}.{f}"] = t
         if on_ready is not None:
             on_ready({f"layers.{i}.{f}": t for f, t in gr.items()})
     if lowest < 0:
-        want = needd["pre_w"] or needd["pre_b"]
-        demb, dg, db = ops.layernorm_bwd(dx, emb, p.pre_w, m0, r0, need_param_grads=want)
-        if want:
-            grads["pre_w"], grads["pre_b"] = dg, db
+        demb = _ln_bwd(dx, emb, p.pre_w, m0, r0, None, bool(needd["pre_w"] or needd["pre_b"]), grads, "pre_w", "pre_b", alloc)
         if needd["pos"] or needd["class_embedding"]:
-            dpos = ops.colsum(demb.view(B, S * D))
+            dpos = ops.colsum(demb.view(B, S * D), out=(_galloc(alloc, "pos", (S * D,), dev) if needd["pos"] else None))
             if needd["pos"]:
                 grads["pos"] = dpos.view(S, D)
             if needd["class_embedding"]:
-                grads["class_embedding"] = dpos[:D].clone()
+                ce = _galloc(alloc, "class_embedding", (D,), dev)
+                ce.copy_(dpos[:D])
+                grads["class_embedding"] = ce
         if needd["patch_w"]:
             dpatch = ops.vision_assemble_bwd(demb, B, S, D)
-            grads["patch_w"] = ops.gemm(dpatch, cols, ops.LAYOUT_TN).view_as(p.patch_w)
+            pw = _galloc(alloc, "patch_w", (D, p.patch_w.numel() // D), dev)
+            grads["patch_w"] = ops.gemm(dpatch, cols, ops.LAYOUT_TN, out=pw).view_as(p.patch_w)
         if on_ready is not None:
             on_ready({n: grads[n] for n in VisionParams.HEAD if grads[n] is not None})
     return [grads[n] for n in names]

@@ -16,8 +16,20 @@ _GRAD_READY_HOOK = None
 
 
 def set_grad_ready_hook(fn):
+    """`fn([(Parameter, gradient), ...]) -> bool`: True = the hook OWNS these gradients from here on (it will set
+    `.grad` itself, e.g. to a slice of a reduced bucket) and the tower's backward returns None for them to autograd."""
     global _GRAD_READY_HOOK
     _GRAD_READY_HOOK = fn
+
+
+# Where the hand-written backward writes a parameter's gradient: `fn(Parameter, shape) -> tensor or None`
+# (dist.GradSync.grad_buffer: the parameter's slice of its persistent all-reduce bucket).  None = fresh tensors.
+_GRAD_ALLOC = None
+
+
+def set_grad_alloc(fn):
+    global _GRAD_ALLOC
+    _GRAD_ALLOC = fn
 
 
 def _c(t: torch.Tensor) -> torch.Tensor:
@@ -38,13 +50,23 @@ class VisionTowerFn(torch.autograd.Function):
     def backward(ctx, d_out):
         if ctx.saved is None:
             raise RuntimeError("VisionTowerFn.backward called twice, or forward ran without grad")
-        on_ready = None
-        if _GRAD_READY_HOOK is not None:
+        on_ready = alloc = None
+        owned = set()
+        if _GRAD_READY_HOOK is not None or _GRAD_ALLOC is not None:
             by_name = dict(zip(ctx.p.names(), ctx.param_refs))
+        if _GRAD_READY_HOOK is not None:
             hook = _GRAD_READY_HOOK
-            on_ready = lambda named: hook([(by_name[n], g) for n, g in named.items()])      # noqa: E731
-        grads = engine.vision_bwd(ctx.p, ctx.saved, _c(d_out), ctx.cfg, list(ctx.needs_input_grad[3:]), on_ready)
+
+            def on_ready(named):
+                if hook([(by_name[n], g) for n, g in named.items()]):
+                    owned.update(named)
+        if _GRAD_ALLOC is not None:
+            galloc = _GRAD_ALLOC
+            alloc = lambda name, shape: galloc(by_name[name], shape)      # noqa: E731
+        grads = engine.vision_bwd(ctx.p, ctx.saved, _c(d_out), ctx.cfg, list(ctx.needs_input_grad[3:]), on_ready, alloc)
         ctx.saved = None
+        if owned:           # handed to the data-parallel reducer: autograd neither accumulates nor clones them
+            grads = [None if n in owned else g for n, g in zip(ctx.p.names(), grads)]
         return (None, None, None, *grads)
 
 
@@ -65,13 +87,19 @@ class VisionTowerBf16Fn(torch.autograd.Function):
         if ctx.saved is None:
             raise RuntimeError("VisionTowerBf16Fn.backward called twice")
         on_ready = None
+        owned = set()
         if _GRAD_READY_HOOK is not None:
             by_name = dict(zip(ctx.p.names(), ctx.param_refs))
             hook = _GRAD_READY_HOOK
-            on_ready = lambda named: hook([(by_name[n], g) for n, g in named.items()])      # noqa: E731
+
+            def on_ready(named):
+                if hook([(by_name[n], g) for n, g in named.items()]):
+                    owned.update(named)
         grads = engine.vision_bwd_bf16(ctx.p, ctx.saved, _c(d_out), ctx.cfg, list(ctx.needs_input_grad[4:]), ctx.cache,
                                        on_ready)
         ctx.saved = None
+        if owned:
+            grads = [None if n in owned else g for n, g in zip(ctx.p.names(), grads)]
         return (None, None, None, None, *grads)
 
 

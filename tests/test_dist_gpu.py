@@ -55,10 +55,15 @@ def _worker(rank, world, port, B, out, overlap):
     sync = ddist.GradSync(trainable, dist.group.WORLD, bucket_mb=0.05)
     if overlap:
         functional.set_grad_ready_hook(sync.on_grads_ready)      # all-reduce launched from inside the backward
+        functional.set_grad_alloc(sync.grad_buffer)              # gradients written straight into the buckets
     share = mod.training_step(shard)
     share.backward()
     sync.finish()
     functional.set_grad_ready_hook(None)
+    functional.set_grad_alloc(None)
+    st = sync.stats()
+    if overlap:      # every gradient of the hooked tower was produced in place: no packing copy
+        assert st["grad_tensors_written_in_place_per_step"] >= 30 and st["grad_tensors_copied_per_step"] == 0, st
     tot = share.detach().clone()
     dist.all_reduce(tot)
     torch.cuda.synchronize()
@@ -98,10 +103,12 @@ def _rccl_worker(rank, world, port, B, out):
     trainable = [p for p in mod.parameters() if p.requires_grad]
     sync = ddist.GradSync(trainable, group, bucket_mb=0.05)
     functional.set_grad_ready_hook(sync.on_grads_ready)
+    functional.set_grad_alloc(sync.grad_buffer)
     share = mod.training_step(shard)
     share.backward()
     sync.finish()
     functional.set_grad_ready_hook(None)
+    functional.set_grad_alloc(None)
     tot = share.detach().clone()
     dist.all_reduce(tot, group=group)
     torch.cuda.synchronize()
