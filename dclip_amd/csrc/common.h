@@ -69,8 +69,11 @@ __device__ __forceinline__ float quarter_max(float v) {
   return v;
 }
 
-__device__ __forceinline__ float quick_gelu_f(float x) { return x / (1.0f + __expf(-1.702f * x)); }
+// x * sigmoid(1.702 x) (hf:activations.py:122-123).  The sigmoid's reciprocal is v_rcp_f32 (1 ulp): the IEEE division
+// sequence is ~10 instructions per element, and an epilogue wave beside MFMA-issuing waves gets one instruction through
+// every ~45 cycles (tools/gemm_stamps.py) — instruction count is what the epilogue costs.
+__device__ __forceinline__ float quick_gelu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * x)); }
 __device__ __forceinline__ float quick_gelu_grad_f(float x) {
-  float s = 1.0f / (1.0f + __expf(-1.702f * x));
+  float s = __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * x));
   return s * (1.0f + 1.702f * x * (1.0f - s));
 }

@@ -20,6 +20,8 @@
 
 namespace {
 
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+
 constexpr int BK = 32;
 
 struct GemmParams {
@@ -46,6 +48,7 @@ struct GemmParams {
   float* part_s;         // mode 1: [tiles_n*WN][M] sum exp(z - max)
   int offset;            // column of row i's positive = i + offset
   const int32_t* gt;     // mode 3: per-row ground-truth column, excluded from the count (nullptr = row index)
+  unsigned magic_per_group;   // floor(2^32 / (group_m * tiles_n)), filled in by launch_cfg
 #ifdef DCLIP_GEMM_STAMPS
   int dbg;               // diagnostic ablations (WRONG results): 1 no epilogue, 2 no DMA in the K loop, 4 no K-loop barrier,
                          // 8 DMA pieces fetched out of range (issue + zero fill, no memory traffic)
@@ -63,7 +66,7 @@ __device__ unsigned long long* g_stamps = nullptr;
 #define GEMM_STAMP_V(slot, value)                                                              \
   do {                                                                                         \
     if (threadIdx.x == 0 && g_stamps)                                                          \
-      g_stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + (slot)] = (value);          \
+      g_stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 16 + (slot)] = (value);         \
   } while (0)
 #define GEMM_STAMP(slot) GEMM_STAMP_V(slot, __builtin_amdgcn_s_memtime())
 #define GEMM_STAMP_RT(slot) GEMM_STAMP_V(slot, __builtin_amdgcn_s_memrealtime())
@@ -123,6 +126,10 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) gemm_f32_kernel(GemmParams p)
 
   GEMM_STAMP(0);
   GEMM_STAMP_RT(4);
+  // (A wave that is NOT in its K loop shares its SIMD with waves issuing an MFMA every 64 cycles and gets an instruction
+  // through only every 50-200 cycles — tools/gemm_stamps.py: ~14 k cycles of prologue and ~13 k of epilogue around a
+  // 145 k-cycle K loop at K = 768.  Raising its priority with s_setprio 3 outside the K loop changed nothing (A/B within
+  // +-0.5 % on every shape), so what is left is to keep prologue and epilogue SHORT in instructions.)
   const int nwg = p.tiles_m * p.tiles_n;
   // Each XCD walks a contiguous range of `swz`; inside it tiles are visited in groups of GROUP_M tile-rows, column
   // by column, so the ~64 workgroups resident on one XCD cover an ~8x8 patch of tiles: every A / B panel slice
@@ -130,21 +137,30 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) gemm_f32_kernel(GemmParams p)
   const int GROUP_M = p.group_m;
   const int swz = xcd_remap(blockIdx.x, nwg);
   const int per_group = GROUP_M * p.tiles_n;
-  const int first_m = (swz / per_group) * GROUP_M;
+  // swz / per_group by the host's floor(2^32 / per_group): a scalar multiply-high and one correction instead of an
+  // integer-division sequence (every instruction of the prologue costs tens of cycles beside MFMA-issuing waves)
+  int grp = (int)__umulhi((unsigned)swz, p.magic_per_group);
+  int rem = swz - grp * per_group;
+  if (rem >= per_group) {
+    rem -= per_group;
+    ++grp;
+  }
+  const int first_m = grp * GROUP_M;
   const int gsize = min(GROUP_M, p.tiles_m - first_m);
-  const int tile_m = first_m + (swz % per_group) % gsize, tile_n = (swz % per_group) / gsize;
+  int tile_m, tile_n;
+  if (gsize == 8) {             // every full group of the default rasterisation
+    tile_m = first_m + (rem & 7);
+    tile_n = rem >> 3;
+  } else {
+    tile_m = first_m + rem % gsize;
+    tile_n = rem / gsize;
+  }
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int kbeg = blockIdx.y * p.k_per_split;
   const int kend = min(p.K, kbeg + p.k_per_split);
   const int nk = (kend - kbeg + BK - 1) / BK;
 
-  f32x16 acc[MT][NT];
-#pragma unroll
-  for (int i = 0; i < MT; ++i)
-#pragma unroll
-    for (int j = 0; j < NT; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  f32x16 acc[MT][NT];   // zeroed BEHIND the first tile's loads (below): those v_movs then cost nothing
 
   // DCLIP_EPI_A_ROWSUM: sum_k A[m][k] is accumulated from the staged chunks of a [K][M]-major A while they sit in
   // registers (every chunk of a thread covers the same 4 columns m: 256 % (BM/4) == 0); the workgroups of tile
@@ -407,9 +423,32 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) gemm_f32_kernel(GemmParams p)
   };
 
   const bool k_ragged = (A_KMAJOR || B_KMAJOR) && (kspan % BK) != 0;  // only the last tile can be partial
-  load_tile(0);
-  if (k_ragged && nk == 1) store_tile(0, 0, true);
-  else store_tile(0, 0, false);
+  GEMM_STAMP(8);                       // setup done (descriptors, offsets)
+  // First K-tile.  The LDS-DMA kernels fetch it by DMA as well when it is a full tile (no staging registers, no
+  // ds_write); either way the accumulators are zeroed while the loads are in flight.
+  const bool dma0 = DMA && !do_rs && !(k_ragged && nk == 1);
+  if (dma0) {
+#pragma unroll
+    for (int c = 0; c < A_CHUNKS + B_CHUNKS; ++c) dma_chunk(0, 0, c);
+  } else {
+    load_tile(0);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  __builtin_amdgcn_sched_barrier(0);
+  GEMM_STAMP(9);
+  if (dma0) {
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+  } else {
+    if (k_ragged && nk == 1) store_tile(0, 0, true);
+    else store_tile(0, 0, false);
+  }
+  GEMM_STAMP(10);
   __syncthreads();
   GEMM_STAMP(1);
   int kt = 0;
@@ -554,46 +593,104 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) gemm_f32_kernel(GemmParams p)
 #pragma unroll
         for (int r = 0; r < 16; ++r)
           ct[(wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * BN + wn * TN + j * 32 + l31] = acc[i][j][r];
+    GEMM_STAMP(11);                    // accumulators written to LDS (includes the wait for the last MFMAs)
     __syncthreads();
+    GEMM_STAMP(12);
+    // Row stores.  A wave that is not issuing MFMAs gets an instruction through every ~45 cycles while its neighbours
+    // on the SIMD are in their K loops (tools/gemm_stamps.py: 9-10 k cycles for this phase with the generic, flag-testing
+    // loop), so the epilogue is written for INSTRUCTION COUNT: one buffer descriptor per tensor based at the tile origin,
+    // one per-thread byte offset, the chunk step in a scalar offset, the bias loaded once (a thread's chunks share their
+    // columns), and one tight loop per epilogue kind instead of flag tests per chunk.
     constexpr int CHUNKS = BM * BN / 4 / NTHR;
-    const float* s0 = (epi & DCLIP_EPI_DGELU) ? p.aux : p.residual;
-    const bool has_s0 = epi & (DCLIP_EPI_RESIDUAL | DCLIP_EPI_DGELU);
-    f32x4 side[CHUNKS];
-    if (has_s0) {
+    constexpr int RSTEP = NTHR / (BN / 4);                 // rows between a thread's consecutive chunks
+    const int lr0 = tid / (BN / 4), lc = (tid % (BN / 4)) * 4;
+    const float* ctp = ct + lr0 * BN + lc;
+    if (p.slab) {
+      float* sl = p.slab + ((size_t)blockIdx.y * p.M + m0 + lr0) * p.N + n0 + lc;
+#pragma unroll
+      for (int q = 0; q < CHUNKS; ++q)
+        *reinterpret_cast<f32x4*>(sl + (size_t)q * RSTEP * p.N) = *reinterpret_cast<const f32x4*>(ctp + q * RSTEP * BN);
+      GEMM_STAMP(3);
+      GEMM_STAMP_RT(5);
+      return;
+    }
+    const int tile_bytes = (int)(((size_t)(BM - 1) * p.ldc + BN) * 4);
+    const size_t org = (size_t)m0 * p.ldc + n0;
+    auto tile_rsrc = [&](const float* base) {
+      return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base + org), 0, tile_bytes, 0x00020000);
+    };
+    const int voff = (lr0 * p.ldc + lc) * 4;
+    const int sstep = RSTEP * p.ldc * 4;
+    auto ld4 = [&](__amdgpu_buffer_rsrc_t r, int q) {
+      return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, q * sstep, 0));
+    };
+    auto st4 = [&](__amdgpu_buffer_rsrc_t r, int q, f32x4 v) {
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), r, voff, q * sstep, 0);
+    };
+    const __amdgpu_buffer_rsrc_t c_rsrc = tile_rsrc(p.C);
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (epi & DCLIP_EPI_BIAS) bv = *reinterpret_cast<const f32x4*>(p.bias + n0 + lc);
+    const float alpha = p.alpha;
+    const int kind = epi & (DCLIP_EPI_GELU | DCLIP_EPI_DGELU | DCLIP_EPI_RESIDUAL | DCLIP_EPI_ACCUM);
+    if (kind == 0) {                                        // [bias]: qkv projection, plain dgrads
+#pragma unroll
+      for (int q = 0; q < CHUNKS; ++q) st4(c_rsrc, q, *reinterpret_cast<const f32x4*>(ctp + q * RSTEP * BN) * alpha + bv);
+    } else if (kind == DCLIP_EPI_RESIDUAL) {                // [bias] + residual: out_proj, fc2, dgrad + skip gradient
+      const __amdgpu_buffer_rsrc_t r_rsrc = tile_rsrc(p.residual);
+      f32x4 side[CHUNKS];
+#pragma unroll
+      for (int q = 0; q < CHUNKS; ++q) side[q] = ld4(r_rsrc, q);
+#pragma unroll
+      for (int q = 0; q < CHUNKS; ++q)
+        st4(c_rsrc, q, *reinterpret_cast<const f32x4*>(ctp + q * RSTEP * BN) * alpha + bv + side[q]);
+    } else if (kind == DCLIP_EPI_GELU) {                    // [bias] + quick-GELU, pre-activation kept in aux: fc1
+      const bool keep = p.aux != nullptr;
+      const __amdgpu_buffer_rsrc_t a_rsrc2 = tile_rsrc(keep ? p.aux : p.C);
 #pragma unroll
       for (int q = 0; q < CHUNKS; ++q) {
-        const int id = tid + q * NTHR;
-        const int row = m0 + id / (BN / 4), col = n0 + (id % (BN / 4)) * 4;
-        side[q] = *reinterpret_cast<const f32x4*>(s0 + (size_t)row * p.ldc + col);
-      }
-    }
-#pragma unroll
-    for (int q = 0; q < CHUNKS; ++q) {
-      const int id = tid + q * NTHR;
-      const int lr = id / (BN / 4), lc = (id % (BN / 4)) * 4;
-      const int row = m0 + lr, col = n0 + lc;
-      f32x4 v = *reinterpret_cast<const f32x4*>(ct + lr * BN + lc);
-      if (p.slab) {
-        *reinterpret_cast<f32x4*>(p.slab + ((size_t)blockIdx.y * p.M + row) * p.N + col) = v;
-        continue;
-      }
-      const size_t off = (size_t)row * p.ldc + col;
-      v = v * p.alpha;
-      if (epi & DCLIP_EPI_BIAS) v += *reinterpret_cast<const f32x4*>(p.bias + col);
-      if (epi & DCLIP_EPI_GELU) {
-        if (p.aux) *reinterpret_cast<f32x4*>(p.aux + off) = v;
+        f32x4 v = *reinterpret_cast<const f32x4*>(ctp + q * RSTEP * BN) * alpha + bv;
+        if (keep) st4(a_rsrc2, q, v);
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = quick_gelu_f(v[e]);
+        st4(c_rsrc, q, v);
       }
-      if (epi & DCLIP_EPI_DGELU) {
+    } else if (kind == DCLIP_EPI_DGELU) {                   // x quick-GELU'(aux): fc2 dgrad
+      const __amdgpu_buffer_rsrc_t a_rsrc2 = tile_rsrc(p.aux);
+      f32x4 side[CHUNKS];
+#pragma unroll
+      for (int q = 0; q < CHUNKS; ++q) side[q] = ld4(a_rsrc2, q);
+#pragma unroll
+      for (int q = 0; q < CHUNKS; ++q) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(ctp + q * RSTEP * BN) * alpha + bv;
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] *= quick_gelu_grad_f(side[q][e]);
-        if (epi & DCLIP_EPI_RESIDUAL) v += *reinterpret_cast<const f32x4*>(p.residual + off);
-      } else if (epi & DCLIP_EPI_RESIDUAL) {
-        v += side[q];
+        st4(c_rsrc, q, v);
       }
-      if (epi & DCLIP_EPI_ACCUM) v += *reinterpret_cast<const f32x4*>(p.C + off);
-      *reinterpret_cast<f32x4*>(p.C + off) = v;
+    } else {                                                // any other combination: the general form
+      const float* s0 = (epi & DCLIP_EPI_DGELU) ? p.aux : p.residual;
+      const bool has_s0 = epi & (DCLIP_EPI_RESIDUAL | DCLIP_EPI_DGELU);
+#pragma unroll
+      for (int q = 0; q < CHUNKS; ++q) {
+        const int row = m0 + lr0 + q * RSTEP, col = n0 + lc;
+        const size_t off = (size_t)row * p.ldc + col;
+        f32x4 v = *reinterpret_cast<const f32x4*>(ctp + q * RSTEP * BN) * alpha + bv;
+        f32x4 sd = {0.f, 0.f, 0.f, 0.f};
+        if (has_s0) sd = *reinterpret_cast<const f32x4*>(s0 + off);
+        if (epi & DCLIP_EPI_GELU) {
+          if (p.aux) *reinterpret_cast<f32x4*>(p.aux + off) = v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = quick_gelu_f(v[e]);
+        }
+        if (epi & DCLIP_EPI_DGELU) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] *= quick_gelu_grad_f(sd[e]);
+          if (epi & DCLIP_EPI_RESIDUAL) v += *reinterpret_cast<const f32x4*>(p.residual + off);
+        } else if (epi & DCLIP_EPI_RESIDUAL) {
+          v += sd;
+        }
+        if (epi & DCLIP_EPI_ACCUM) v += *reinterpret_cast<const f32x4*>(p.C + off);
+        *reinterpret_cast<f32x4*>(p.C + off) = v;
+      }
     }
     GEMM_STAMP(3);
     GEMM_STAMP_RT(5);
@@ -680,7 +777,10 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(GemmParams p, int sp
 }
 
 template <int BM, int BN, int WM, int WN>
-int launch_cfg(const GemmParams& p, int layout, int splits, hipStream_t st) {
+int launch_cfg(const GemmParams& p_in, int layout, int splits, hipStream_t st) {
+  GemmParams p = p_in;
+  p.magic_per_group = (unsigned)(0x100000000ull / (unsigned long long)(p.group_m * p.tiles_n));
+
   dim3 grid(p.tiles_m * p.tiles_n, splits);
   const size_t lds = (size_t)2 * (BM + BN) * BK * sizeof(float);
   const bool ak = layout & DCLIP_A_KMAJOR, bk = layout & DCLIP_B_KMAJOR;
@@ -761,7 +861,7 @@ Plan make_plan(int M, int N, int K, int layout, int split_k) {
 }  // namespace
 
 #ifdef DCLIP_GEMM_STAMPS
-// [workgroups][8] uint64 on the device, or nullptr to stop stamping (diagnostic library only)
+// [workgroups][16] uint64 on the device, or nullptr to stop stamping (diagnostic library only)
 DCLIP_API int dclip_debug_set_gemm_stamps(void* buf) {
   return hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &buf, sizeof(buf)) == hipSuccess ? DCLIP_OK : DCLIP_ELAUNCH;
 }

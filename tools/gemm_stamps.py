@@ -42,7 +42,7 @@ SHAPES = {
     "big": [("8192^3 NT", 3, 8192, 8192, 8192)],
 }
 MAXWG = 1 << 16
-stamps = torch.zeros((MAXWG, 8), dtype=torch.int64, device=dev)
+stamps = torch.zeros((MAXWG, 16), dtype=torch.int64, device=dev)
 for name, layout, m, n, k in SHAPES[args.shapes]:
     a = torch.randn((m, k) if layout & 1 else (k, m), device=dev)
     b = torch.randn((n, k) if layout & 2 else (k, n), device=dev)
@@ -101,6 +101,13 @@ for name, layout, m, n, k in SHAPES[args.shapes]:
     q = lambda x: f"{np.percentile(x, 10):8.0f}/{np.median(x):8.0f}/{np.percentile(x, 90):8.0f}"
     print(f"    cycles p10/median/p90: prologue {q(pro)}  loop {q(loop)} ({np.median(loop) / nk:7.0f}/K-tile, MFMA floor "
           f"{floor_cyc_per_ktile:.0f} x co-resident WGs)  epilogue {q(epi)}")
+    s8, s9, s10, s11, s12 = [s[:, i] for i in range(8, 13)]
+    ok = s11 > 0            # interior tiles only carry the epilogue sub-stamps
+    print(f"    prologue split (median cycles): setup {np.median(s8 - t0):6.0f} | first tile issued + acc zeroed {np.median(s9 - s8):6.0f} | "
+          f"landed / LDS store {np.median(s10 - s9):6.0f} | barrier {np.median(t1 - s10):6.0f}")
+    if ok.any():
+        print(f"    epilogue split (median cycles): acc->LDS (incl. MFMA drain) {np.median((s11 - t2)[ok]):6.0f} | barrier "
+              f"{np.median((s12 - s11)[ok]):6.0f} | side loads + row stores {np.median((t3 - s12)[ok]):6.0f}")
     vmw, brw = (tile >> 20) & 0x3FFFFF, (tile >> 42) & 0x3FFFFF
     print(f"    wave 0, per K-tile: vmcnt(0) wait {np.median(vmw) / nk:6.0f} cyc  barrier wait {np.median(brw) / nk:6.0f} cyc "
           f"(p90 {np.percentile(vmw, 90) / nk:6.0f} / {np.percentile(brw, 90) / nk:6.0f})")
