@@ -149,3 +149,25 @@ def test_module_dataloaders(tmp_path):
     pv, caps, paths, boxes = next(iter(m.val_dataloader()))
     assert pv.shape == (3, 3, 224, 224) and len(caps) == 3 and boxes[0] == full[paths[0]]
     assert len(list(m.train_dataloader())) == 3                                # 7 items, batch 3 (eval_batch_size, N3)
+
+
+def test_zero_shot_image_folder_transform(tmp_path):
+    """ImageFolderDataset = torchvision ImageFolder + Resize(S) + CenterCrop(S) + ToTensor()
+    (eval_scripts/test_zero_shot_ImageNet.py:141-151): shortest edge to S (long edge int(S*long/short)), bilinear,
+    centred window, [0,1] floats, sorted class folders."""
+    import numpy as np
+    from PIL import Image
+    from dclip_amd import synth
+    from dclip_amd.zero_shot_eval import ImageFolderDataset, make_prompts
+    for c, (h, w) in (("b_dog", (50, 80)), ("a_cat", (90, 60))):
+        (tmp_path / c).mkdir()
+        Image.fromarray(synth.synth_photo(h, w, seed=h)).save(tmp_path / c / "0.png")
+    ds = ImageFolderDataset(str(tmp_path), 32)
+    assert ds.classes == ["a_cat", "b_dog"] and len(ds) == 2
+    x, y = ds[0]
+    assert y == 0 and tuple(x.shape) == (3, 32, 32) and 0.0 <= float(x.min()) and float(x.max()) <= 1.0
+    im = Image.open(tmp_path / "a_cat" / "0.png").convert("RGB")            # 60 wide, 90 high -> 32 x 48 -> rows 8..40
+    want = np.asarray(im.resize((32, 48), Image.BILINEAR).crop((0, 8, 32, 40)), dtype=np.float32) / 255.0
+    assert np.array_equal(x.permute(1, 2, 0).numpy(), want)
+    assert make_prompts(["cat"]) == ["a photo of a cat"]
+    assert make_prompts(["cat"], "CIFAR-10") == ["a photo of a cat, a type of object"]

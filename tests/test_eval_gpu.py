@@ -127,3 +127,64 @@ def test_flickr_eval_flow_base_and_checkpoint(tmp_path):
     sim2 = -sim                                                   # negated image embeddings flip every similarity
     t2i_rank2 = [(sim2[c] > sim2[c, owner[c]]).sum().item() for c in range(len(caps))]
     assert abs(m2["t2i"]["MAP"] - np.mean([1.0 / (r + 1) for r in t2i_rank2])) < 1e-9
+
+
+def test_zero_shot_script_flow_base_and_checkpoint(tmp_path):
+    """eval_scripts/test_zero_shot_ImageNet.py / CIFAR_zeroshot.py as a flow: class folders -> Resize + CenterCrop +
+    ToTensor -> mean/std -> embeddings -> top-1 / top-5, for the base model and a Lightning-layout checkpoint; checked
+    against a dense similarity matrix + topk."""
+    import argparse
+    from PIL import Image
+    from dclip_amd import config as dcfg, synth, zero_shot_eval as Z
+    from dclip_amd.CLIP_image_distillation import CLIPImageDistillation
+    from dclip_amd.clip_model import from_hf_state_dict
+    from dclip_amd.lightning_lite import save_checkpoint
+    dev = torch.device("cuda:0")
+    cfg = dcfg.tiny(image_size=64, patch_size=16)
+    clip = from_hf_state_dict(cfg, synth.synth_clip_state_dict(cfg, seed=3, gain=3.0), device=dev)
+    names = ["cat", "dog", "tree", "car", "bird", "boat", "cup"]
+    k = 0
+    for c in names:
+        (tmp_path / "val" / c).mkdir(parents=True)
+        for j in range(3):
+            Image.fromarray(synth.synth_photo(70 + 5 * k, 90 + 3 * k, seed=k)).save(tmp_path / "val" / c / f"{j}.png")
+            k += 1
+    (tmp_path / "classes.txt").write_text("\n".join(sorted(names)) + "\n")
+    T = cfg.text.max_position_embeddings
+
+    def toy_processor(text=None, return_tensors="pt", padding=True):
+        ids = torch.full((len(text), T), cfg.text.eos_token_id, dtype=torch.int64)
+        ids[:, 0] = cfg.text.bos_token_id
+        for b, c in enumerate(text):
+            for j, w in enumerate(c.replace(",", " ").split()[:T - 2]):
+                ids[b, 1 + j] = 1 + (sum(ord(ch) * (q + 1) for q, ch in enumerate(w)) % (cfg.text.bos_token_id - 2))
+        return {"input_ids": ids}
+
+    for dataset, suffix in (("imagenet", ""), ("cifar10", ", a type of object")):
+        res = Z.main(["--data_root", str(tmp_path / "val"), "--classnames", str(tmp_path / "classes.txt"), "--dataset", dataset,
+                      "--batch_size", "4", "--results", str(tmp_path / f"{dataset}.txt")], clip_model=clip, processor=toy_processor)
+        ds = Z.ImageFolderDataset(str(tmp_path / "val"), 64)
+        assert ds.classes == sorted(names) and len(ds) == 21
+        x = torch.stack([ds[i][0] for i in range(len(ds))]).to(dev)
+        y = torch.tensor([ds[i][1] for i in range(len(ds))])
+        mean = torch.tensor(Z.E.CLIP_MEAN, device=dev).view(1, 3, 1, 1)
+        std = torch.tensor(Z.E.CLIP_STD, device=dev).view(1, 3, 1, 1)
+        with torch.no_grad():
+            img = clip.get_image_features(pixel_values=(x - mean) / std).double().cpu()
+            txt = clip.get_text_features(input_ids=toy_processor([f"a photo of a {n}{suffix}" for n in sorted(names)])["input_ids"]
+                                         .to(dev)).double().cpu()
+        sim = 100.0 * torch.nn.functional.normalize(img, dim=1) @ torch.nn.functional.normalize(txt, dim=1).t()
+        top5 = sim.topk(5, dim=1).indices
+        assert abs(res["base"]["top1"] - float((top5[:, 0] == y).float().mean())) < 1e-12
+        assert abs(res["base"]["top5"] - float((top5 == y[:, None]).any(1).float().mean())) < 1e-12
+        assert "base Top-1" in (tmp_path / f"{dataset}.txt").read_text()
+    hp = argparse.Namespace(learning_rate=1e-4, warmup_steps=0, total_steps=10, train_batch_size=4, eval_batch_size=4)
+    mod = CLIPImageDistillation(hp, clip, None).to(dev)
+    with torch.no_grad():
+        mod.student.visual_projection.weight.mul_(-1.0)
+    ck = save_checkpoint(str(tmp_path / "ck" / "epoch-epoch=00-train_loss=1.00.ckpt"), mod)
+    base2 = from_hf_state_dict(cfg, synth.synth_clip_state_dict(cfg, seed=3, gain=3.0), device=dev)
+    res2 = Z.main(["--data_root", str(tmp_path / "val"), "--checkpoint", ck, "--batch_size", "8", "--results",
+                   str(tmp_path / "r2.txt")], clip_model=base2, processor=toy_processor)
+    assert set(res2) == {"base", "custom"} and 0.0 <= res2["custom"]["top1"] <= res2["custom"]["top5"] <= 1.0
+    assert res2["custom"]["top5"] != res2["base"]["top5"] or res2["custom"]["top1"] != res2["base"]["top1"]
