@@ -175,8 +175,8 @@ def test_zero_shot_script_flow_base_and_checkpoint(tmp_path):
                                          .to(dev)).double().cpu()
         sim = 100.0 * torch.nn.functional.normalize(img, dim=1) @ torch.nn.functional.normalize(txt, dim=1).t()
         top5 = sim.topk(5, dim=1).indices
-        assert abs(res["base"]["top1"] - float((top5[:, 0] == y).float().mean())) < 1e-12
-        assert abs(res["base"]["top5"] - float((top5 == y[:, None]).any(1).float().mean())) < 1e-12
+        assert abs(res["base"]["top1"] - float((top5[:, 0] == y).double().mean())) < 1e-12
+        assert abs(res["base"]["top5"] - float((top5 == y[:, None]).any(1).double().mean())) < 1e-12
         assert "base Top-1" in (tmp_path / f"{dataset}.txt").read_text()
     hp = argparse.Namespace(learning_rate=1e-4, warmup_steps=0, total_steps=10, train_batch_size=4, eval_batch_size=4)
     mod = CLIPImageDistillation(hp, clip, None).to(dev)
