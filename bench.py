@@ -197,6 +197,10 @@ def main():
     ap.add_argument("--no-extra-legs", action="store_true",
                     help="skip the untimed-by-the-contract extra measurements after the timed region (forward+backward "
                          "without the optimizer; HIP-graph replay)")
+    ap.add_argument("--eager", action="store_true",
+                    help="launch every step kernel by kernel.  Default at N=1 on the benched workload: forward+backward are "
+                         "replayed from a captured HIP graph (bit-identical to the eager step, dclip_amd/graph.py) and every "
+                         "5th step of the timed region runs eagerly with HIP events around each GEMM launch")
     ap.add_argument("--graph", action="store_true",
                     help="replay forward+backward from a captured HIP graph (dclip_amd/graph.py; N=1 only).  Per-launch "
                          "GEMM events do not exist inside a graph: `roofline` is then taken from an eager pass of the "
@@ -307,7 +311,35 @@ def main():
             p_.grad = None
         graphed = GraphedStep(module, batch)
 
-    def step(with_opt=True):
+    # Default execution at N = 1 (c2): HIP-graph replay of forward + backward, with every `stride`-th step of the timed
+    # region launched eagerly so that the GEMM launches of that step can be bracketed by HIP events.
+    hybrid = None
+    exec_note = "eager launches"
+    if graphed is None and world == 1 and not meta and not args.eager and opt is not None:
+        try:
+            from dclip_amd.graph import GraphedStep
+            for p_ in trainable:
+                p_.grad = None
+            hybrid = GraphedStep(module, batch)
+            hybrid_grads = [(p_, p_.grad) for p_ in trainable if p_.grad is not None]     # the graph's static gradients
+            exec_note = "HIP-graph replay of forward+backward; sampled steps launched eagerly (per-launch GEMM events)"
+        except Exception as exc:            # a box where capture fails still gets its eager number
+            hybrid = None
+            exec_note = f"eager launches (HIP-graph capture failed: {type(exc).__name__}: {exc})"[:240]
+            for p_ in trainable:
+                p_.grad = None
+
+    def step(with_opt=True, eager_now=False):
+        if hybrid is not None and not eager_now:
+            for p_, g_ in hybrid_grads:          # an eager step in between left .grad at None
+                p_.grad = g_
+            loss = hybrid.step()
+            if with_opt:
+                opt.step()
+            return loss
+        if hybrid is not None:                   # the eager step of the hybrid schedule: fresh gradient tensors
+            for p_ in trainable:
+                p_.grad = None
         if graphed is not None:
             loss = graphed.step()                # inputs already sit in the captured buffers
             if opt is not None and with_opt:
@@ -361,7 +393,7 @@ def main():
         timer.enabled = on
         sampled["n"] += int(on)
         sampled["i"] += 1
-        return step()
+        return step(eager_now=on)
 
     elapsed, last = timed(args.steps, timed_step)      # ---- THE timed region: exactly K steps
     timer.enabled = False
@@ -379,7 +411,11 @@ def main():
             extra["fwd_bwd_ms_per_step"] = round(el * 1e3 / n_x, 3)
             extra["fwd_bwd_images_per_s"] = round(world * B * n_x / el, 2)
             extra["optimizer_ms_per_step"] = round(elapsed * 1e3 / args.steps - el * 1e3 / n_x, 3)
-        if world == 1 and not meta:          # the meta-teacher sizes its token padding on the host: not capturable
+        if hybrid is not None:               # the all-eager figure beside the default (graph) one
+            el, _ = timed(n_x, lambda: step(eager_now=True))
+            extra["eager_ms_per_step"] = round(el * 1e3 / n_x, 3)
+            extra["eager_images_per_s"] = round(B * n_x / el, 2)
+        if world == 1 and not meta and hybrid is None:     # (meta-teacher: host-sized token padding, not capturable)
             try:
                 from dclip_amd.graph import GraphedStep
                 for p_ in trainable:
@@ -453,6 +489,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": wl + ("fwd+bwd only" if opt is None else "fwd+bwd + clip-norm 0.5 + AdamW")
                                    + (", fwd+bwd replayed from a HIP graph" if graphed is not None else ""),
+                       "execution": exec_note,
                        "global_batch": world * B, "parallelism": f"dp{world}",
                        "loss": last_loss},
             "roofline": {"bound": "mfma", "kernel": "gemm_f32_kernel (v_mfma_f32_32x32x2_f32)",
