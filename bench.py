@@ -27,6 +27,10 @@ sys.path.insert(0, REPO)
 # pool's boxes; set here as well so a bare launch behaves the same)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
+if os.environ.get("DCLIP_BENCH_TRACE_AFTER") and "RANK" in os.environ:   # debugging aid (ranks only): dump the Python stacks after N s, exit
+    import faulthandler
+    faulthandler.dump_traceback_later(int(os.environ["DCLIP_BENCH_TRACE_AFTER"]), exit=True)
+
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 

@@ -91,3 +91,50 @@ def test_single_process_path_matches_oracle():
     ref.backward()
     assert abs(float(loss) - float(ref)) < 1e-5
     assert torch.allclose(img.grad, i2.grad, rtol=1e-4, atol=1e-7) and torch.allclose(txt.grad, t2.grad, rtol=1e-4, atol=1e-7)
+
+
+def _bucket_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from dclip_amd import dist as ddist
+    ps = [torch.nn.Parameter(torch.zeros(n)) for n in (1000, 7, 30000, 64, 25000, 3, 9000)]
+    sync = ddist.GradSync(ps, dist.group.WORLD, bucket_mb=0.05)
+    ok = True
+    for step in range(4):                       # the buckets are persistent: several backward / finish rounds
+        pairs = []
+        for i, p in enumerate(reversed(ps)):    # deliveries in backward order; one gradient is NOT produced in place
+            buf = sync.grad_buffer(p, tuple(p.shape))
+            if i == 2:
+                g = torch.full_like(p, float(rank + 1 + step))
+            else:
+                buf.fill_(float(rank + 1 + step))
+                g = buf
+            pairs.append((p, g))
+        for k in range(0, len(pairs) - 1, 2):
+            assert sync.on_grads_ready(pairs[k:k + 2]) is True
+        ps[0].grad = pairs[-1][1].clone()       # the last parameter arrives through .grad (no hook), as another tower's would
+        sync.finish()
+        want = float(sum(r + 1 + step for r in range(world)))
+        ok = ok and all(bool(torch.all(p.grad == want)) for p in ps)
+        ok = ok and all(p.grad.data_ptr() == sync.grad_buffer(p, tuple(p.shape)).data_ptr() for p in ps)
+    stats = sync.stats()
+    try:
+        sync.on_grads_ready([(ps[1], torch.ones(7))])
+        sync.on_grads_ready([(ps[1], torch.ones(7))])
+        ok = False
+    except RuntimeError:                        # a second delivery in one backward is refused, not dropped
+        pass
+    out[rank] = dict(ok=ok, stats=stats)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_gradsync_persistent_buckets_over_several_steps(world):
+    out = mp.Manager().dict()
+    mp.spawn(_bucket_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    for r in range(world):
+        assert out[r]["ok"], r
+        st = out[r]["stats"]
+        assert st["grad_buckets_per_step"] >= 3 and st["grad_tensors_copied_per_step"] == 2.0      # the two not in place
+        assert st["grad_tensors_written_in_place_per_step"] == 5.0
