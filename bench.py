@@ -324,9 +324,16 @@ def main():
             from dclip_amd.graph import GraphedStep
             for p_ in trainable:
                 p_.grad = None
-            hybrid = GraphedStep(module, batch)
+            # inside the replayed graph the frozen text tower's forward runs on a second stream beside the vision forward;
+            # the eager (sampled, event-bracketed) steps launch every kernel alone on one stream
+            module.overlap_frozen_text = not os.environ.get("DCLIP_NO_TEXT_OVERLAP")
+            try:
+                hybrid = GraphedStep(module, batch)
+            finally:
+                module.overlap_frozen_text = False
             hybrid_grads = [(p_, p_.grad) for p_ in trainable if p_.grad is not None]     # the graph's static gradients
-            exec_note = "HIP-graph replay of forward+backward; sampled steps launched eagerly (per-launch GEMM events)"
+            exec_note = ("HIP-graph replay of forward+backward (frozen text forward on a second stream beside the vision forward); "
+                         "sampled steps launched eagerly, one stream, per-launch GEMM events")
         except Exception as exc:            # a box where capture fails still gets its eager number
             hybrid = None
             exec_note = f"eager launches (HIP-graph capture failed: {type(exc).__name__}: {exc})"[:240]

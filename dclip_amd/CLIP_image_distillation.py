@@ -81,6 +81,12 @@ class CLIPImageDistillation(LightningLikeModule):
         if student_precision not in ("fp32", "bf16"):
             raise ValueError(f"student_precision {student_precision!r}")
         self.student_precision = student_precision
+        # Run the FROZEN text tower's forward on a second HIP stream beside the vision tower's forward (they share nothing
+        # until the loss): the two GEMM chains fill each other's tile-round tails and per-workgroup prologue / epilogue gaps.
+        # Off by default — per-kernel timings (bench.py's GEMM events, rocprof) are only meaningful for kernels that run
+        # alone; bench.py switches it on for the captured HIP graph it replays.
+        self.overlap_frozen_text = False
+        self._text_stream = None
         self.save_hyperparameters(hparams, ignore="clip_model")
         self.student = _as_hip_model(clip_model)
         self.preprocess = clip_preprocess
@@ -200,8 +206,6 @@ class CLIPImageDistillation(LightningLikeModule):
                 teacher_image = self.teacher_bridge(teacher_image)
             if teacher_text is not None and teacher_text.shape[1] != self.student.config.projection_dim:
                 teacher_text = self.teacher_bridge(teacher_text)
-        student_image = self.student.get_image_features(pixel_values=images, precision=self.student_precision).float()
-        loss_image = self.cosine_distillation_loss(student_image, teacher_image)
         shared_sentence = None
         if ran_teacher and self.teacher.shares_text_tower_with(self.student) \
                 and getattr(self.teacher.text_tokenizer, "precision", "fp32") == "fp32":
@@ -209,12 +213,30 @@ class CLIPImageDistillation(LightningLikeModule):
             # embeddings; the sentence embedding is row first-EOS of that pass.  One text forward serves the teacher's
             # tokens, the teacher's sentence target and the (frozen) student text features.
             shared_sentence = self.teacher.last_sentence_embedding
+        text_frozen = not any(p.requires_grad for p in self.student.text_model.parameters()) \
+            and not self.student.text_projection.weight.requires_grad
+        text_precision = "bf16" if (self.student_precision == "bf16" and text_frozen) else "fp32"
+        text_job = None
+        if shared_sentence is None and text_frozen and self.overlap_frozen_text and tokens.is_cuda:
+            main = torch.cuda.current_stream(dev)
+            if self._text_stream is None:
+                self._text_stream = torch.cuda.Stream(device=dev)
+            self._text_stream.wait_stream(main)                      # fork: the token ids are ready
+            from . import ops
+            with torch.cuda.stream(self._text_stream), torch.no_grad(), ops.workspace_lane(1):     # own scratch: concurrent
+                text_job = self.student.get_text_features(input_ids=tokens, precision=text_precision).float()
+        student_image = self.student.get_image_features(pixel_values=images, precision=self.student_precision).float()
+        loss_image = self.cosine_distillation_loss(student_image, teacher_image)
         if shared_sentence is not None:
             student_text = shared_sentence.float()
-        elif self.student_precision == "bf16" and not any(p.requires_grad for p in self.student.text_model.parameters()) \
-                and not self.student.text_projection.weight.requires_grad:
-            with torch.no_grad():          # frozen text tower of a bf16 student: bf16 GEMM inputs there as well
-                student_text = self.student.get_text_features(input_ids=tokens, precision="bf16").float()
+        elif text_job is not None:
+            main = torch.cuda.current_stream(dev)
+            main.wait_stream(self._text_stream)                      # join
+            text_job.record_stream(main)
+            student_text = text_job
+        elif text_frozen:
+            with torch.no_grad():          # frozen text tower (of a bf16 student: bf16 GEMM inputs there as well)
+                student_text = self.student.get_text_features(input_ids=tokens, precision=text_precision).float()
         else:
             student_text = self.student.get_text_features(input_ids=tokens).float()
         if teacher_text is None:

@@ -63,6 +63,27 @@ class _Workspace:
 
 
 _ws = _Workspace()
+_ws_lanes = {0: _ws}
+
+
+class workspace_lane:
+    """Launch sequences that run CONCURRENTLY on different streams must not share scratch memory (split-K slabs,
+    LayerNorm / column-sum partials): `with ops.workspace_lane(1): ...` gives the enclosed launches a workspace of their
+    own (grow-only like lane 0; sized by an eager warm-up before any HIP-graph capture)."""
+
+    def __init__(self, lane: int):
+        self.lane = lane
+
+    def __enter__(self):
+        global _ws
+        self.prev = _ws
+        _ws = _ws_lanes.setdefault(self.lane, _Workspace())
+        return self
+
+    def __exit__(self, *exc):
+        global _ws
+        _ws = self.prev
+        return False
 
 
 # ------------------------------------------------------------------------------------------- GEMM
