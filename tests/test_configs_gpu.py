@@ -269,3 +269,31 @@ def test_c2_full_size_step_vs_oracle_and_properties():
     hi, dhi = ops.contrastive_lse(ihat[h:].contiguous(), that, h, 20.0)
     assert torch.allclose(torch.cat([lo, hi]), full_i, rtol=1e-6, atol=1e-6)
     assert torch.allclose(torch.cat([dlo, dhi]), diag, rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.timeout(900)
+def test_c4_full_per_gpu_size_forward_vs_oracle():
+    """BASELINE config c4's per-GPU work at ITS size (ViT-B/16, 128 pairs per GPU of the 1024 global batch): image / text
+    embeddings and the local cosine + contrastive losses against the CPU oracle (forward only there)."""
+    import os
+    from dclip_amd.clip_model import from_hf_state_dict
+    from dclip_amd.CLIP_image_distillation import distill_losses
+    dev = torch.device("cuda:0")
+    cfg = dcfg.vit_b16()
+    sd = synth.synth_clip_state_dict(cfg, seed=1, gain=3.0)
+    m = from_hf_state_dict(cfg, sd, device=dev)
+    B = 128
+    pix = synth.synth_pixel_values(B, cfg.vision, seed=4)
+    ids = synth.synth_input_ids(B, cfg.text, seed=104)
+    t_img = synth.synth_embeddings(B, cfg.projection_dim, seed=1004)
+    with torch.no_grad():
+        img = m.get_image_features(pixel_values=pix.to(dev))
+        txt = m.get_text_features(input_ids=ids.to(dev))
+        out = distill_losses(img, txt, t_img.to(dev), txt)
+    torch.set_num_threads(max(1, min(32, len(os.sched_getaffinity(0)))))
+    with torch.no_grad():
+        ref = O.distill_step(sd, cfg, pix, ids, t_img)
+    assert _rel(img, ref["image_emb"]) < 1e-3 and _rel(txt, ref["text_emb"]) < 1e-3
+    for k in ("loss_image", "loss_contrastive", "loss"):
+        got, want = float(out[k]), float(ref[k])
+        assert abs(got - want) <= 1e-3 * max(abs(want), 1e-3), (k, got, want)
