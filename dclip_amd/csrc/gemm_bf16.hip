@@ -440,6 +440,288 @@ int launch_dma(GemmBf16Params p, hipStream_t st) {
   return DCLIP_OK;
 }
 
+#define PP_BARRIER()                      \
+  do {                                    \
+    __builtin_amdgcn_sched_barrier(0);    \
+    __builtin_amdgcn_s_barrier();         \
+    __builtin_amdgcn_sched_barrier(0);    \
+  } while (0)
+
+// Epilogue of the ping-pong kernel: one wave row (128 x 256 fp32 = the whole LDS) per pass through the dead staging
+// buffers.  A thread keeps ONE column group (4 columns) and walks 16 rows, 8 apart: the bias is loaded once, and the side
+// operand of a pass (KIND 3 residual, KIND 2 saved pre-activation) is fetched into registers — unconditionally, from
+// clamped addresses — BEFORE that pass's stores: vmcnt counts loads and stores together in issue order, so a load
+// issued behind stores waits for every one of them, and a load under a per-element condition is waited for alone.
+// KIND 0 bias only, 1 quick-GELU (pre-activation saved to aux when given), 2 x dGELU(aux), 3 + residual.
+template <int KIND, bool OUT16>
+__device__ __forceinline__ void pp_epilogue(const GemmBf16Params& p, const f32x4 (&acc)[8][4], float* ct, int m0, int n0,
+                                            int tid, int wr, int wc, int quad, int l15) {
+  constexpr int BN = 256;
+  const int lc = (tid & 63) * 4, col = n0 + lc, lr0 = tid >> 6;
+  const bool colok = col < p.N;                     // N % 4 == 0: a column group is inside or outside as a whole
+  const int colc = colok ? col : 0;
+  f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+  if (p.epilogue & DCLIP_EPI_BIAS) bias4 = *reinterpret_cast<const f32x4*>(p.bias + colc);
+#pragma unroll
+  for (int hm = 0; hm < 2; ++hm) {
+    const int rbase = m0 + hm * 128 + lr0;
+    f32x4 side[KIND == 3 ? 16 : 1];
+    u16x4 side16[KIND == 2 ? 16 : 1];
+    if (KIND == 3) {
+#pragma unroll
+      for (int q = 0; q < 16; ++q)
+        side[q] = *reinterpret_cast<const f32x4*>(p.residual + (size_t)min(rbase + 8 * q, p.M - 1) * p.ldc + colc);
+    }
+    if (KIND == 2) {
+#pragma unroll
+      for (int q = 0; q < 16; ++q)
+        side16[q] = *reinterpret_cast<const u16x4*>(p.aux + (size_t)min(rbase + 8 * q, p.M - 1) * p.ldc + colc);
+    }
+    if (wr == hm) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) ct[(16 * i + 4 * quad + r) * BN + 64 * wc + 16 * j + l15] = acc[i][j][r];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    PP_BARRIER();
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int row = rbase + 8 * q;
+      f32x4 v = *reinterpret_cast<const f32x4*>(ct + (lr0 + 8 * q) * BN + lc) + bias4;
+      const size_t off = (size_t)row * p.ldc + col;
+      const bool ok = row < p.M && colok;
+      if (KIND == 1) {
+        if (p.aux) {
+          u16x4 h = {f32_to_bf16_bits(v[0]), f32_to_bf16_bits(v[1]), f32_to_bf16_bits(v[2]), f32_to_bf16_bits(v[3])};
+          if (ok) *reinterpret_cast<u16x4*>(p.aux + off) = h;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = __builtin_bit_cast(float, (unsigned int)h[e] << 16);   // gelu of what was saved
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = quick_gelu_f(v[e]);
+      }
+      if (KIND == 2) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] *= quick_gelu_grad_f(__builtin_bit_cast(float, (unsigned int)side16[q][e] << 16));
+      }
+      if (KIND == 3) v += side[q];
+      if (!ok) continue;
+      if (OUT16) {
+        u16x4 o = {f32_to_bf16_bits(v[0]), f32_to_bf16_bits(v[1]), f32_to_bf16_bits(v[2]), f32_to_bf16_bits(v[3])};
+        *reinterpret_cast<u16x4*>(reinterpret_cast<unsigned short*>(p.C) + off) = o;
+      } else {
+        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + off) = v;
+      }
+    }
+    if (hm == 0) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // pass 0's LDS reads are done before pass 1 overwrites them
+      PP_BARRIER();
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Ping-pong variant of the 256x256x64 tile (8 waves = 2 x 4, wave tile 128x64, v_mfma_f32_16x16x32_bf16): the two
+// waves of a SIMD belong to different wave rows (wr = wave >> 2) and run ONE BARRIER APART, so that while one issues
+// its LDS fragment reads and the next LDS-DMA pieces the other has the matrix pipe — the K loop of the kernel above
+// runs both waves of a SIMD in step (one barrier per K-tile) and measures ~4.2k cycles per K-tile against the 2,048
+// of the MFMAs alone.  Per K-tile four phases, one 64x32 quadrant of the wave tile each (16 MFMAs = 256 cycles):
+//     phase 1  read B(qn 0) 4 + A(qm 0) 8 fragments | DMA A-half 1 of tile kt+1 | MFMA quadrant (0,0)
+//     phase 2  read B(qn 1) 4                         | DMA B-half 0 of tile kt+2 | MFMA (0,1)
+//     phase 3  read A(qm 1) 8                         | DMA A-half 0 of tile kt+2 | MFMA (1,1)
+//     phase 4  -                                      | DMA B-half 1 of tile kt+2, vmcnt(6) | MFMA (1,0)
+// each phase = [reads + DMA issue] barrier [lgkmcnt(0), MFMAs] barrier.  A "half" is the set of rows every wave needs
+// for its quadrant row / column h (A: rows with bit 6 == h, B: rows with bit 5 == h), 16 DMA pieces = 2 per wave.
+// Ordering (DMA data is ordered for a ds_read only by the issuing waves' counted vmcnt followed by a barrier the reader
+// has passed; the groups are a barrier apart, so reads come one PHASE after the wait):
+//   RAW  phase 4's vmcnt(6) leaves the three half-tiles of kt+2 in flight and retires all of kt+1, read from phase 1 of
+//        kt+1 on; the last tiles wait vmcnt(0).
+//   WAR  a half is re-staged two phases after its last read (A0: read phase 1, staged phase 3; B1: 2 -> 4; A1: 3 -> 1
+//        of the next tile), B0 one phase after (read first in phase 1 and retired by lgkmcnt(8) BEFORE that phase's
+//        first barrier).
+// Every wave executes the same number of s_barrier: wave row 1 one extra before the loop, wave row 0 one after it.
+__global__ void __launch_bounds__(512) gemm_bf16_pp_kernel(GemmBf16Params p) {
+  constexpr int BM = 256, BN = 256, ROW = BKH;
+  constexpr int BUF = (BM + BN) * ROW;   // bf16 elements per K-tile buffer: 256 A rows then 256 B rows of 128 bytes
+  __shared__ __attribute__((aligned(16))) unsigned char lds_raw[2 * BUF * 2];   // 128 KiB: the ONLY LDS object
+  __bf16* lds = reinterpret_cast<__bf16*>(lds_raw);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int l15 = lane & 15, quad = lane >> 4;
+
+  constexpr int GROUP_M = 8;
+  const int nwg = p.tiles_m * p.tiles_n;
+  const int swz = xcd_remap16(blockIdx.x, nwg);
+  const int per_group = GROUP_M * p.tiles_n;
+  const int first_m = (swz / per_group) * GROUP_M;
+  const int gsize = min(GROUP_M, p.tiles_m - first_m);
+  const int tile_m = first_m + (swz % per_group) % gsize, tile_n = (swz % per_group) / gsize;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int nk = p.K / BKH;
+
+  const __bf16* a_org = p.A + (size_t)m0 * p.lda;
+  const __bf16* w_org = p.W + (size_t)n0 * p.ldw;
+  const int a_rows = min(BM, p.M - m0), w_rows = min(BN, p.N - n0);
+  const size_t a_bytes = ((size_t)(a_rows - 1) * p.lda + p.K) * 2, w_bytes = ((size_t)(w_rows - 1) * p.ldw + p.K) * 2;
+  const __amdgpu_buffer_rsrc_t a_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a_org), 0, (int)min(a_bytes, (size_t)0x7fffffff), 0x00020000);
+  const __amdgpu_buffer_rsrc_t w_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(w_org), 0, (int)min(w_bytes, (size_t)0x7fffffff), 0x00020000);
+  // DMA pieces (8 rows x 128 B, lane i -> row i >> 3, stored slot i & 7 = logical granule slot ^ ((row >> 1) & 7)).
+  // A-half h: piece x of this wave covers rows 128 x + 64 h + 8 wave; B-half h: rows 64 (2 x + (wave >> 2)) + 32 h + 8 (wave & 3).
+  int a_voff[2][2], w_voff[2][2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int x = 0; x < 2; ++x) {
+      const int ra = 128 * x + 64 * h + 8 * wave + (lane >> 3), ga = (lane & 7) ^ ((ra >> 1) & 7);
+      a_voff[h][x] = ra < a_rows ? (ra * p.lda + ga * 8) * 2 : 0x7fffffff;   // out of range -> zeros in LDS
+      const int rb = 64 * (2 * x + (wave >> 2)) + 32 * h + 8 * (wave & 3) + (lane >> 3), gb = (lane & 7) ^ ((rb >> 1) & 7);
+      w_voff[h][x] = rb < w_rows ? (rb * p.ldw + gb * 8) * 2 : 0x7fffffff;
+    }
+#define PP_ISSUE_A(h, buf, kt)                                                                                          \
+  do {                                                                                                                  \
+    dma16(a_rsrc, lds + (buf) * BUF + (64 * (h) + 8 * wave) * ROW, a_voff[h][0], (kt) * (BKH * 2));                     \
+    dma16(a_rsrc, lds + (buf) * BUF + (128 + 64 * (h) + 8 * wave) * ROW, a_voff[h][1], (kt) * (BKH * 2));               \
+  } while (0)
+#define PP_ISSUE_B(h, buf, kt)                                                                                          \
+  do {                                                                                                                  \
+    dma16(w_rsrc, lds + (buf) * BUF + (BM + 64 * (wave >> 2) + 32 * (h) + 8 * (wave & 3)) * ROW, w_voff[h][0],          \
+          (kt) * (BKH * 2));                                                                                            \
+    dma16(w_rsrc, lds + (buf) * BUF + (BM + 128 + 64 * (wave >> 2) + 32 * (h) + 8 * (wave & 3)) * ROW, w_voff[h][1],    \
+          (kt) * (BKH * 2));                                                                                            \
+  } while (0)
+
+  // fragment addresses: row 16 blk + l15, k-step s: logical granule 4 s + quad, stored at granule ^ (l15 >> 1)
+  const int sw = l15 >> 1;
+  const __bf16* pa0 = lds + (128 * wr + l15) * ROW + (((0 + quad) ^ sw) << 3);
+  const __bf16* pa1 = lds + (128 * wr + l15) * ROW + (((4 + quad) ^ sw) << 3);
+  const __bf16* pb0 = lds + (BM + 64 * wc + l15) * ROW + (((0 + quad) ^ sw) << 3);
+  const __bf16* pb1 = lds + (BM + 64 * wc + l15) * ROW + (((4 + quad) ^ sw) << 3);
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  bf16x8 fa[4][2], fb0[2][2], fb1[2][2];
+
+#define PP_READ_A(qm, off)                                                                          \
+  _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                   \
+    fa[i][0] = *reinterpret_cast<const bf16x8*>(pa0 + (off) + (64 * (qm) + 16 * i) * ROW);          \
+    fa[i][1] = *reinterpret_cast<const bf16x8*>(pa1 + (off) + (64 * (qm) + 16 * i) * ROW);          \
+  }
+#define PP_READ_B(fb, qn, off)                                                                      \
+  _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                   \
+    fb[j][0] = *reinterpret_cast<const bf16x8*>(pb0 + (off) + (32 * (qn) + 16 * j) * ROW);          \
+    fb[j][1] = *reinterpret_cast<const bf16x8*>(pb1 + (off) + (32 * (qn) + 16 * j) * ROW);          \
+  }
+#define PP_MFMA(qm, qn, fb)                                                                                         \
+  do {                                                                                                              \
+    __builtin_amdgcn_s_setprio(1);                                                                                  \
+    _Pragma("unroll") for (int s = 0; s < 2; ++s)                                                                   \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                   \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                   \
+      acc[4 * (qm) + i][2 * (qn) + j] =                                                                             \
+          __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][s], fb[j][s], acc[4 * (qm) + i][2 * (qn) + j], 0, 0, 0);    \
+    __builtin_amdgcn_s_setprio(0);                                                                                  \
+  } while (0)
+
+  // prologue: all of tile 0 and three halves of tile 1 (the fourth goes out in phase 1 of tile 0)
+  PP_ISSUE_A(0, 0, 0);
+  PP_ISSUE_B(0, 0, 0);
+  PP_ISSUE_B(1, 0, 0);
+  PP_ISSUE_A(1, 0, 0);
+  if (nk > 1) {
+    PP_ISSUE_B(0, 1, 1);
+    PP_ISSUE_A(0, 1, 1);
+    PP_ISSUE_B(1, 1, 1);
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  PP_BARRIER();
+  if (wr == 1) PP_BARRIER();   // wave row 1 runs one barrier behind wave row 0
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1, off = cur * BUF;
+    const bool n1 = kt + 1 < nk, n2 = kt + 2 < nk;
+    // ---- phase 1
+    PP_READ_B(fb0, 0, off);
+    __builtin_amdgcn_sched_barrier(0);
+    PP_READ_A(0, off);
+    __builtin_amdgcn_sched_barrier(0);
+    if (n1) PP_ISSUE_A(1, cur ^ 1, kt + 1);
+    asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");   // the B reads are done: their rows may be re-staged next phase
+    PP_BARRIER();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    PP_MFMA(0, 0, fb0);
+    PP_BARRIER();
+    // ---- phase 2
+    PP_READ_B(fb1, 1, off);
+    __builtin_amdgcn_sched_barrier(0);
+    if (n2) PP_ISSUE_B(0, cur, kt + 2);
+    PP_BARRIER();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    PP_MFMA(0, 1, fb1);
+    PP_BARRIER();
+    // ---- phase 3
+    PP_READ_A(1, off);
+    __builtin_amdgcn_sched_barrier(0);
+    if (n2) PP_ISSUE_A(0, cur, kt + 2);
+    PP_BARRIER();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    PP_MFMA(1, 1, fb1);
+    PP_BARRIER();
+    // ---- phase 4
+    if (n2) {
+      PP_ISSUE_B(1, cur, kt + 2);
+      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // tile kt+1 has landed (this wave's pieces)
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    PP_BARRIER();
+    PP_MFMA(1, 0, fb0);
+    PP_BARRIER();
+  }
+  if (wr == 0) PP_BARRIER();   // balance the stagger: everybody is past its last MFMA phase and LDS read
+#undef PP_ISSUE_A
+#undef PP_ISSUE_B
+#undef PP_READ_A
+#undef PP_READ_B
+#undef PP_MFMA
+
+  // ---- epilogue (pp_epilogue above), one instance per epilogue kind and output type
+  const int kind = (p.epilogue & DCLIP_EPI_RESIDUAL) ? 3 : (p.epilogue & DCLIP_EPI_DGELU) ? 2 : (p.epilogue & DCLIP_EPI_GELU) ? 1 : 0;
+  float* ct = reinterpret_cast<float*>(lds_raw);
+  if (p.out_bf16) {
+    if (kind == 0) pp_epilogue<0, true>(p, acc, ct, m0, n0, tid, wr, wc, quad, l15);
+    else if (kind == 1) pp_epilogue<1, true>(p, acc, ct, m0, n0, tid, wr, wc, quad, l15);
+    else pp_epilogue<2, true>(p, acc, ct, m0, n0, tid, wr, wc, quad, l15);          // RESIDUAL needs an fp32 output (host check)
+  } else {
+    if (kind == 0) pp_epilogue<0, false>(p, acc, ct, m0, n0, tid, wr, wc, quad, l15);
+    else if (kind == 1) pp_epilogue<1, false>(p, acc, ct, m0, n0, tid, wr, wc, quad, l15);
+    else if (kind == 2) pp_epilogue<2, false>(p, acc, ct, m0, n0, tid, wr, wc, quad, l15);
+    else pp_epilogue<3, false>(p, acc, ct, m0, n0, tid, wr, wc, quad, l15);
+  }
+}
+#undef PP_BARRIER
+
+int launch_pp(GemmBf16Params p, hipStream_t st) {
+  p.tiles_m = cdiv(p.M, 256);
+  p.tiles_n = cdiv(p.N, 256);
+  hipLaunchKernelGGL(gemm_bf16_pp_kernel, dim3(p.tiles_m * p.tiles_n), dim3(512), 0, st, p);
+  return DCLIP_OK;
+}
+
 // y[i] = bf16(x[i]); rows of `cols` floats written with leading dimension ldy (>= cols, zero padded)
 __global__ void __launch_bounds__(256) cast_bf16_kernel(const float* __restrict__ x, unsigned short* __restrict__ y, int rows,
                                                         int cols, int ldx, int ldy) {
@@ -551,7 +833,9 @@ DCLIP_API int dclip_gemm_bf16_ex(const void* A, const void* W, void* C, const fl
   if (K % BKH == 0 && (long)cdiv(M, 256) * cdiv(N, 256) >= big_min) {
     GemmBf16Params pb{(const __bf16*)A, (const __bf16*)W, C, bias, residual, M, N, K, lda, ldw, ldc, epilogue, out_bf16, 0, 0,
                       (unsigned short*)aux, 0, nullptr};
-    launch_dma<256, 256, 2, 4>(pb, st);
+    static const bool pingpong = !(getenv("DCLIP_BF16_PP") && atoi(getenv("DCLIP_BF16_PP")) == 0);   // A/B switch
+    if (pingpong) launch_pp(pb, st);
+    else launch_dma<256, 256, 2, 4>(pb, st);
     DCLIP_CHECK_LAUNCH("gemm_bf16.dma");
     return DCLIP_OK;
   }

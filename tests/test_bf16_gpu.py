@@ -116,16 +116,19 @@ def test_meta_teacher_bf16_towers_close_to_fp32():
     assert float(cos.min()) > 0.999
 
 
-def test_gemm_bf16_big_tile_kernel_matches(monkeypatch):
-    """The 256x256 LDS-DMA kernel, forced onto small shapes (DCLIP_BF16_BIG_MIN=1 is read once per process: this test
-    runs the comparison in a child process), against the fp64 product of the rounded inputs."""
+@pytest.mark.parametrize("pingpong", ["1", "0"])
+def test_gemm_bf16_big_tile_kernel_matches(pingpong):
+    """The 256x256 LDS-DMA kernels (ping-pong schedule, and the lock-step one behind DCLIP_BF16_PP=0), forced onto small
+    shapes (DCLIP_BF16_BIG_MIN=1 is read once per process: this test runs the comparison in a child process), against
+    the fp64 product of the rounded inputs.  K = 64 .. 3072 covers 1, 2, 3 (odd), 12 and 48 K-tiles."""
     import subprocess, sys, os, textwrap
     code = textwrap.dedent("""
         import torch, sys
         sys.path.insert(0, %r)
         from dclip_amd import ops
         dev = torch.device("cuda:0")
-        for M, N, K in [(256, 256, 64), (1000, 520, 128), (257, 260, 192), (2048, 3072, 768), (4100, 768, 3072), (77, 768, 768)]:
+        for M, N, K in [(256, 256, 64), (1000, 520, 128), (257, 260, 192), (2048, 3072, 768), (4100, 768, 3072), (77, 768, 768),
+                        (511, 508, 320), (300, 1028, 256)]:
             g = torch.Generator().manual_seed(M + N + K)
             a, w = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) * 0.1
             bias, res = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
@@ -139,10 +142,22 @@ def test_gemm_bf16_big_tile_kernel_matches(monkeypatch):
             g16 = ops.gemm_bf16(a16, w16, k=K, bias=bias.to(dev), gelu=True, out_bf16=True)
             ref = (want * torch.sigmoid(1.702 * want)).to(torch.bfloat16)
             assert float((g16.cpu().double() - ref.double()).abs().max() / ref.double().abs().max()) < 1e-2
+            # training epilogues: GELU that also saves the bf16 pre-activation; product times quick_gelu'(saved)
+            y, h = ops.gemm_bf16(a16, w16, k=K, bias=bias.to(dev), gelu=True, save_preact=True)
+            h_ref = want.to(torch.bfloat16)
+            assert float((h.cpu().double() - h_ref.double()).abs().max() / h_ref.double().abs().max()) < 1e-2
+            hd = h.double().cpu()
+            assert float((y.double().cpu() - hd * torch.sigmoid(1.702 * hd)).abs().max()) < 1e-4 * float(hd.abs().max())
+            sg = torch.sigmoid(1.702 * hd)
+            dref = (want - bias.double()) * (sg * (1.0 + 1.702 * hd * (1.0 - sg)))
+            for o16 in (False, True):
+                d = ops.gemm_bf16(a16, w16, k=K, dgelu_of=h, out_bf16=o16)
+                tol = 1e-2 if o16 else 1e-5
+                assert float((d.double().cpu() - dref).abs().max() / dref.abs().max()) < tol, (M, N, K, o16)
         print("OK")
     """) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, DCLIP_BF16_BIG_MIN="1")
-    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+    env = dict(os.environ, DCLIP_BF16_BIG_MIN="1", DCLIP_BF16_PP=pingpong)
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
     assert p.returncode == 0 and "OK" in p.stdout, p.stdout[-2000:] + p.stderr[-2000:]
 
 
