@@ -562,12 +562,16 @@ __global__ void __launch_bounds__(512) gemm_bf16_pp_kernel(GemmBf16Params p) {
   const int gsize = min(GROUP_M, p.tiles_m - first_m);
   const int tile_m = first_m + (swz % per_group) % gsize, tile_n = (swz % per_group) / gsize;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
-  const int nk = p.K / BKH;
+  // split-K (gridDim.y > 1): this work item contracts k in [kbeg, kbeg + kspan), both multiples of 64 (host check)
+  const int kbeg = p.k_per_split ? blockIdx.y * p.k_per_split : 0;
+  const int kspan = (p.k_per_split ? min(p.K, kbeg + p.k_per_split) : p.K) - kbeg;
+  const int nk = kspan / BKH;
 
-  const __bf16* a_org = p.A + (size_t)m0 * p.lda;
-  const __bf16* w_org = p.W + (size_t)n0 * p.ldw;
+  const __bf16* a_org = p.A + (size_t)m0 * p.lda + kbeg;
+  const __bf16* w_org = p.W + (size_t)n0 * p.ldw + kbeg;
   const int a_rows = min(BM, p.M - m0), w_rows = min(BN, p.N - n0);
-  const size_t a_bytes = ((size_t)(a_rows - 1) * p.lda + p.K) * 2, w_bytes = ((size_t)(w_rows - 1) * p.ldw + p.K) * 2;
+  const size_t a_bytes = ((size_t)(a_rows - 1) * p.lda + (p.K - kbeg)) * 2,
+               w_bytes = ((size_t)(w_rows - 1) * p.ldw + (p.K - kbeg)) * 2;
   const __amdgpu_buffer_rsrc_t a_rsrc =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a_org), 0, (int)min(a_bytes, (size_t)0x7fffffff), 0x00020000);
   const __amdgpu_buffer_rsrc_t w_rsrc =
@@ -702,6 +706,14 @@ __global__ void __launch_bounds__(512) gemm_bf16_pp_kernel(GemmBf16Params p) {
   // ---- epilogue (pp_epilogue above), one instance per epilogue kind and output type
   const int kind = (p.epilogue & DCLIP_EPI_RESIDUAL) ? 3 : (p.epilogue & DCLIP_EPI_DGELU) ? 2 : (p.epilogue & DCLIP_EPI_GELU) ? 1 : 0;
   float* ct = reinterpret_cast<float*>(lds_raw);
+  if (p.slab) {   // split-K partial: raw accumulators into this split's [M][N] slab, the reduce kernel finishes
+    GemmBf16Params ps = p;
+    ps.C = p.slab + (size_t)blockIdx.y * p.M * p.N;
+    ps.ldc = p.N;
+    ps.epilogue = 0;
+    pp_epilogue<0, false>(ps, acc, ct, m0, n0, tid, wr, wc, quad, l15);
+    return;
+  }
   if (p.out_bf16) {
     if (kind == 0) pp_epilogue<0, true>(p, acc, ct, m0, n0, tid, wr, wc, quad, l15);
     else if (kind == 1) pp_epilogue<1, true>(p, acc, ct, m0, n0, tid, wr, wc, quad, l15);
@@ -715,11 +727,17 @@ __global__ void __launch_bounds__(512) gemm_bf16_pp_kernel(GemmBf16Params p) {
 }
 #undef PP_BARRIER
 
-int launch_pp(GemmBf16Params p, hipStream_t st) {
+int launch_pp(GemmBf16Params p, hipStream_t st, int splits = 1) {
   p.tiles_m = cdiv(p.M, 256);
   p.tiles_n = cdiv(p.N, 256);
-  hipLaunchKernelGGL(gemm_bf16_pp_kernel, dim3(p.tiles_m * p.tiles_n), dim3(512), 0, st, p);
+  hipLaunchKernelGGL(gemm_bf16_pp_kernel, dim3(p.tiles_m * p.tiles_n, splits), dim3(512), 0, st, p);
   return DCLIP_OK;
+}
+
+// A/B switch: DCLIP_BF16_PP=0 selects the lock-step 256x256 kernel (and the 128x128 split-K form) instead of the ping-pong one
+bool pingpong_enabled() {
+  static const bool on = !(getenv("DCLIP_BF16_PP") && atoi(getenv("DCLIP_BF16_PP")) == 0);
+  return on;
 }
 
 // y[i] = bf16(x[i]); rows of `cols` floats written with leading dimension ldy (>= cols, zero padded)
@@ -833,8 +851,7 @@ DCLIP_API int dclip_gemm_bf16_ex(const void* A, const void* W, void* C, const fl
   if (K % BKH == 0 && (long)cdiv(M, 256) * cdiv(N, 256) >= big_min) {
     GemmBf16Params pb{(const __bf16*)A, (const __bf16*)W, C, bias, residual, M, N, K, lda, ldw, ldc, epilogue, out_bf16, 0, 0,
                       (unsigned short*)aux, 0, nullptr};
-    static const bool pingpong = !(getenv("DCLIP_BF16_PP") && atoi(getenv("DCLIP_BF16_PP")) == 0);   // A/B switch
-    if (pingpong) launch_pp(pb, st);
+    if (pingpong_enabled()) launch_pp(pb, st);
     else launch_dma<256, 256, 2, 4>(pb, st);
     DCLIP_CHECK_LAUNCH("gemm_bf16.dma");
     return DCLIP_OK;
@@ -890,6 +907,15 @@ DCLIP_API int dclip_layernorm_fwd_bf16_stats(const float* x, const float* gamma,
 // per 128x128 tile write fp32 partials to the caller's workspace, a second kernel sums them in fixed order.  fp32 C, no
 // epilogue.  dclip_gemm_bf16_splitk_plan returns the split count this library would choose (1 = use dclip_gemm_bf16).
 DCLIP_API int dclip_gemm_bf16_splitk_plan(int M, int N, int K) {
+  if (K % BKH == 0 && pingpong_enabled()) {                   // 256x256 ping-pong kernel, one workgroup per CU
+    const long t256 = (long)cdiv(M, 256) * cdiv(N, 256);
+    if (t256 >= 128 || K < 2048) return 1;
+    int s = (int)(256 / t256);
+    const int kmax = K / 512;                                 // at least 8 K-tiles per work item
+    s = s > kmax ? kmax : s;
+    s = s > 64 ? 64 : s;
+    if (s >= 2 && t256 * s >= 128) return s;                  // otherwise too few work items for 256 CUs: 128x128 form below
+  }
   const long tiles = (long)cdiv(M, 128) * cdiv(N, 128);
   if (tiles >= 192 || K < 2048) return 1;
   int s = (int)((768 + tiles - 1) / tiles);                 // ~3 work items per CU
@@ -918,6 +944,16 @@ DCLIP_API int dclip_gemm_bf16_splitk(const void* A, const void* W, float* C, int
     return DCLIP_EWORKSPACE;
   }
   DCLIP_REQUIRE((uintptr_t)workspace % 16 == 0, "gemm_bf16_splitk: workspace must be 16-byte aligned");
+  if (K % BKH == 0 && pingpong_enabled() && (long)cdiv(M, 256) * cdiv(N, 256) * s_eff >= 128) {
+    GemmBf16Params pb{(const __bf16*)A, (const __bf16*)W, C, nullptr, nullptr, M, N, K, lda, ldw, ldc, 0, 0, 0, 0, nullptr, kps,
+                      (float*)workspace};
+    launch_pp(pb, (hipStream_t)stream, s_eff);
+    DCLIP_CHECK_LAUNCH("gemm_bf16_splitk.pp");
+    hipLaunchKernelGGL(splitk_reduce_bf16_kernel, dim3(grid_for((size_t)M * N / 4)), dim3(256), 0, (hipStream_t)stream,
+                       (const float*)workspace, C, M, N, ldc, s_eff);
+    DCLIP_CHECK_LAUNCH("gemm_bf16_splitk.reduce");
+    return DCLIP_OK;
+  }
   GemmBf16Params p{(const __bf16*)A, (const __bf16*)W, C, nullptr, nullptr, M, N, K, lda, ldw, ldc, 0, 0,
                    cdiv(M, 128), cdiv(N, 128), nullptr, kps, (float*)workspace};
   hipStream_t st = (hipStream_t)stream;

@@ -72,7 +72,9 @@ def test_gemm_bf16_preact_and_dgelu(M, N, K):
 
 
 @pytest.mark.parametrize("M,N,K,splits", [(768, 768, 12800, None), (768, 3072, 12800, None), (2304, 768, 12800, 7),
-                                           (128, 256, 85, None), (132, 64, 4100, 3), (768, 768, 12800, 1)])
+                                           (128, 256, 85, None), (132, 64, 4100, 3), (768, 768, 12800, 1),
+                                           (3072, 768, 12800, None), (768, 768, 3200, None), (300, 520, 1280, 3),
+                                           (1024, 4096, 3200, 5)])
 def test_gemm_bf16_wgrad_split_k(M, N, K, splits):
     """dW = dY^T X on token-contiguous bf16 operands, split-K with a fixed-order reduce (deterministic)."""
     from dclip_amd import ops
