@@ -12,6 +12,7 @@
 // the matching A operand V^T[d][those keys] is read straight out of the row-major V tile with the gfx950 transposing
 // LDS read (ds_read_b64_tr_b16: 4 keys x 16 head dims per 16 lanes).
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -168,14 +169,221 @@ __global__ void __launch_bounds__(128) attn_fwd_bf16_kernel(const unsigned short
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Whole-head form for the sequence lengths of the CLIP towers (S <= 288: 50, 77, 197, 257 tokens): one workgroup per
+// (batch, head), one wave per 32 queries (NB = ceil(S / 32) waves), the head's whole K and V staged in LDS ONCE — the
+// tiled kernel above re-reads them once per 64-query tile and pads 257 tokens to 320 on both axes.  With every key
+// on chip the softmax is exact in two passes instead of online: pass 1 forms S^T = K Q^T block by block and keeps only
+// the row maximum (a lane owns one query: 16 v_max per 32-key block, one cross-half shuffle at the end); pass 2 forms
+// the scores again, p = 2^(c s - c max) is one FMA + one v_exp_f32 per score, and P V accumulates with no rescaling of
+// the accumulator and no running statistics — the online form's VALU work (rescale, alpha, masked selects on every
+// block) was twice its MFMA work at head dim 64.  Only the block that holds the sequence end (and, causal, the
+// diagonal block) runs the masked variant.
+template <int NB, bool CAUSAL>
+__global__ void __launch_bounds__(64 * NB) attn_fwd_bf16_head_kernel(const unsigned short* __restrict__ qkv,
+                                                                     unsigned short* __restrict__ out, int S, int H) {
+  __shared__ __attribute__((aligned(16))) unsigned char Ks[NB * 32 * 128];
+  __shared__ __attribute__((aligned(16))) unsigned char Vs[NB * 32 * 128];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, half = lane >> 5;
+  const int bh = blockIdx.x, b = bh / H, h = bh % H;
+  const int D = H * HD, ld = 3 * D;
+  const int query = wave * 32 + l31;
+  const unsigned short* base = qkv + (size_t)b * S * ld + h * HD;
+
+  // Q fragments (B operand): Q[query][16 s + 8 half .. +7] — requested FIRST, in front of the K / V staging loads, so
+  // that they do not become a second round trip to memory behind the barrier
+  bf16x8 qf[4];
+  {
+    const unsigned short* qrow = base + (size_t)min(query, S - 1) * ld + 8 * half;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) qf[s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(qrow + 16 * s));
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  // all eight 16-byte loads of a thread go out together (rows past the end read the last row and are zeroed after: a
+  // load under a per-row condition is waited for on its own — four serial round trips to memory per workgroup)
+  {
+    u32x4 kv[4], vv[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int id = tid + c * (64 * NB), rc = min(id >> 3, S - 1), g = id & 7;
+      kv[c] = *reinterpret_cast<const u32x4*>(base + (size_t)rc * ld + D + g * 8);
+      vv[c] = *reinterpret_cast<const u32x4*>(base + (size_t)rc * ld + 2 * D + g * 8);
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int id = tid + c * (64 * NB), row = id >> 3, g = id & 7;
+      if (row >= S) kv[c] = vv[c] = u32x4{0u, 0u, 0u, 0u};
+      *reinterpret_cast<u32x4*>(Ks + gran_off(row, g)) = kv[c];
+      *reinterpret_cast<u32x4*>(Vs + gran_off(row, g)) = vv[c];
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < 4; ++s) asm volatile("" ::"v"(qf[s]));   // keep the Q loads in front of the barrier (the optimizer sinks them)
+  __syncthreads();
+  if (wave * 32 >= S) return;                      // (never with NB = ceil(S / 32); keeps a mis-sized launch harmless)
+
+  const int last = (S - 1) >> 5;                   // block that holds the last key
+  const int nkb = CAUSAL ? min(wave, last) + 1 : last + 1;
+
+  // K fragments of one 32-key block (A operand of S^T = K Q^T): 4 x ds_read_b128 into the SAME registers every block —
+  // issued right after the block's score MFMAs have consumed the previous contents, so they land behind the softmax
+  // VALU work and the P V MFMAs instead of in front of the next score chain.
+  bf16x8 kf[4];
+  auto load_k = [&](int kb) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+      kf[s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(Ks + gran_off(32 * kb + l31, 2 * s + half)));
+  };
+  auto qk = [&]() {
+    f32x16 st;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) st[r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[s], qf[s], st, 0, 0, 0);
+    return st;
+  };
+  auto valid = [&](int kb, int r) {
+    const int key = 32 * kb + (r & 3) + 8 * (r >> 2) + 4 * half;
+    return key < S && (!CAUSAL || key <= query);
+  };
+  // The last block a wave visits is the only one that can hold masked keys (sequence end; causal: the diagonal): it is
+  // peeled off, the loops over the full blocks before it have no branches.
+  const int nfull = nkb - 1;
+
+  // ---- pass 1: row maximum of the raw scores
+  float mx = -INFINITY;
+  load_k(0);
+  for (int kb = 0; kb < nfull; ++kb) {
+    const f32x16 st = qk();
+    __builtin_amdgcn_sched_barrier(0);
+    load_k(kb + 1);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[r]);
+  }
+  {
+    const f32x16 st = qk();
+    __builtin_amdgcn_sched_barrier(0);
+    load_k(0);                                       // pass 2 starts over
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, valid(nfull, r) ? st[r] : -INFINITY);
+  }
+  mx = fmaxf(mx, __shfl_xor(mx, 32));
+  constexpr float c = kScale * 1.44269504088896341f;   // scale x log2(e)
+  const float nmc = -mx * c;
+
+  // ---- pass 2: p = 2^(c s - c max), row sum, O^T += V^T P^T
+  f32x16 o[2];
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+  float lsum = 0.f;
+  const int i16 = lane & 15, qq = i16 >> 2, pp = i16 & 3;
+  // MFMA step t contracts the keys of registers 8t..8t+7 = {32 kb + 16 t + 4 half + (0..3)} and {.. + 8 + (0..3)}; the
+  // A operand V^T[d][those keys] comes out of the row-major V tile through the transposing read (issued with the next
+  // block's K fragments, before the exponentials)
+  typedef short s16x8 __attribute__((ext_vector_type(8)));
+  s16x8 vf[2][2];
+  auto load_v = [&](int kb) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int k0 = 32 * kb + 16 * t + 4 * half;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        const int dcol = 32 * dt + 16 * ((lane >> 4) & 1) + 4 * pp;   // first head dim of this lane's 8-byte piece
+        const s16x4 lo = lds_tr16(Vs + gran_off(k0 + qq, dcol >> 3) + (dcol & 7) * 2);
+        const s16x4 hi = lds_tr16(Vs + gran_off(k0 + 8 + qq, dcol >> 3) + (dcol & 7) * 2);
+        vf[t][dt] = s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      }
+    }
+  };
+  auto pv = [&](const f32x16& st) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      bf16x8 pf;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) pf[e] = (__bf16)st[8 * t + e];
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+        o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf[t][dt]), pf, o[dt], 0, 0, 0);
+    }
+  };
+  for (int kb = 0; kb < nfull; ++kb) {
+    f32x16 st = qk();
+    __builtin_amdgcn_sched_barrier(0);
+    load_k(kb + 1);
+    load_v(kb);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      st[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[r], c, nmc));
+      lsum += st[r];
+    }
+    pv(st);
+  }
+  {
+    f32x16 st = qk();
+    __builtin_amdgcn_sched_barrier(0);
+    load_v(nfull);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      st[r] = valid(nfull, r) ? __builtin_amdgcn_exp2f(__builtin_fmaf(st[r], c, nmc)) : 0.f;
+      lsum += st[r];
+    }
+    pv(st);
+  }
+  lsum += __shfl_xor(lsum, 32);
+  if (query < S) {
+    const float inv = 1.0f / lsum;
+    unsigned short* orow = out + ((size_t)b * S + query) * D + h * HD;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        u16x4 v = {bf16_bits(o[dt][4 * j + 0] * inv), bf16_bits(o[dt][4 * j + 1] * inv), bf16_bits(o[dt][4 * j + 2] * inv),
+                   bf16_bits(o[dt][4 * j + 3] * inv)};
+        *reinterpret_cast<u16x4*>(orow + 32 * dt + 8 * j + 4 * half) = v;
+      }
+  }
+}
+
+template <int NB>
+void launch_head(const unsigned short* qkv, unsigned short* out, int B, int S, int H, int causal, hipStream_t st) {
+  if (causal) hipLaunchKernelGGL((attn_fwd_bf16_head_kernel<NB, true>), dim3(B * H), dim3(64 * NB), 0, st, qkv, out, S, H);
+  else hipLaunchKernelGGL((attn_fwd_bf16_head_kernel<NB, false>), dim3(B * H), dim3(64 * NB), 0, st, qkv, out, S, H);
+}
+
 }  // namespace
 
 DCLIP_API int dclip_attention_fwd_bf16(const void* qkv, void* out, int B, int S, int H, int causal, void* stream) {
   DCLIP_REQUIRE(qkv && out, "attention_fwd_bf16: null pointer");
   DCLIP_REQUIRE(B > 0 && S > 0 && H > 0, "attention_fwd_bf16: bad shape B=%d S=%d H=%d", B, S, H);
   DCLIP_REQUIRE(((uintptr_t)qkv | (uintptr_t)out) % 16 == 0, "attention_fwd_bf16: 16-byte alignment");
-  dim3 grid(B * H, cdiv(S, 64)), block(128);
   hipStream_t st = (hipStream_t)stream;
+  static const bool tiled_only = getenv("DCLIP_ATTN16_TILED") && atoi(getenv("DCLIP_ATTN16_TILED")) != 0;   // A/B switch
+  if (S <= 288 && !tiled_only) {                    // whole-head kernel: every CLIP tower (50 / 77 / 197 / 257 tokens)
+    const unsigned short* q = (const unsigned short*)qkv;
+    unsigned short* o = (unsigned short*)out;
+    switch (cdiv(S, 32)) {
+      case 1: launch_head<1>(q, o, B, S, H, causal, st); break;
+      case 2: launch_head<2>(q, o, B, S, H, causal, st); break;
+      case 3: launch_head<3>(q, o, B, S, H, causal, st); break;
+      case 4: launch_head<4>(q, o, B, S, H, causal, st); break;
+      case 5: launch_head<5>(q, o, B, S, H, causal, st); break;
+      case 6: launch_head<6>(q, o, B, S, H, causal, st); break;
+      case 7: launch_head<7>(q, o, B, S, H, causal, st); break;
+      case 8: launch_head<8>(q, o, B, S, H, causal, st); break;
+      default: launch_head<9>(q, o, B, S, H, causal, st); break;
+    }
+    DCLIP_CHECK_LAUNCH("attention_fwd_bf16.head");
+    return DCLIP_OK;
+  }
+  dim3 grid(B * H, cdiv(S, 64)), block(128);
   if (causal) hipLaunchKernelGGL((attn_fwd_bf16_kernel<true>), grid, block, 0, st, (const unsigned short*)qkv, (unsigned short*)out, S, H);
   else hipLaunchKernelGGL((attn_fwd_bf16_kernel<false>), grid, block, 0, st, (const unsigned short*)qkv, (unsigned short*)out, S, H);
   DCLIP_CHECK_LAUNCH("attention_fwd_bf16");
