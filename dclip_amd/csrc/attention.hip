@@ -27,16 +27,40 @@ __device__ __forceinline__ int tile_off(int row, int col) {
   return row * HD + ((((col >> 2) ^ (row & 15)) << 2) | (col & 3));
 }
 
-// global rows [row0, row0+64) x 64 floats (row stride ld) -> swizzled LDS tile; rows >= nrows are zero
-__device__ __forceinline__ void stage_tile(float* tile, const float* __restrict__ g, int row0, int nrows, size_t ld) {
+// global rows [row0, row0+64) x 64 floats (row stride ld) -> swizzled LDS tile; rows >= nrows are zero.  In two steps so
+// that the loads of SEVERAL tiles go out together: tile_fetch issues a thread's four 16-byte loads UNCONDITIONALLY (rows
+// past the end read row nrows-1 and are zeroed in tile_commit) — a load under a per-row condition is waited for on its
+// own, which made the staging of a workgroup 4 (per tile) serial round trips to memory.
+__device__ __forceinline__ void tile_fetch(f32x4 (&v)[4], const float* __restrict__ g, int row0, int nrows, size_t ld) {
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
-    int id = threadIdx.x + c * 256;
-    int row = id >> 4, slot = id & 15;
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (row0 + row < nrows) v = *reinterpret_cast<const f32x4*>(g + (size_t)(row0 + row) * ld + slot * 4);
-    *reinterpret_cast<f32x4*>(tile + row * HD + ((slot ^ (row & 15)) << 2)) = v;
+    const int id = threadIdx.x + c * 256;
+    const int row = min(row0 + (id >> 4), nrows - 1), slot = id & 15;
+    v[c] = *reinterpret_cast<const f32x4*>(g + (size_t)row * ld + slot * 4);
   }
+}
+__device__ __forceinline__ void tile_commit(float* tile, f32x4 (&v)[4], int row0, int nrows) {
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int id = threadIdx.x + c * 256;
+    const int row = id >> 4, slot = id & 15;
+    if (row0 + row >= nrows) v[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    *reinterpret_cast<f32x4*>(tile + row * HD + ((slot ^ (row & 15)) << 2)) = v[c];
+  }
+}
+__device__ __forceinline__ void stage_tile(float* tile, const float* __restrict__ g, int row0, int nrows, size_t ld) {
+  f32x4 v[4];
+  tile_fetch(v, g, row0, nrows, ld);
+  tile_commit(tile, v, row0, nrows);
+}
+// two tiles over the same rows (K and V, Q and dO): eight loads in flight
+__device__ __forceinline__ void stage_tiles2(float* ta, const float* __restrict__ ga, size_t lda, float* tb,
+                                             const float* __restrict__ gb, size_t ldb, int row0, int nrows) {
+  f32x4 va[4], vb[4];
+  tile_fetch(va, ga, row0, nrows, lda);
+  tile_fetch(vb, gb, row0, nrows, ldb);
+  tile_commit(ta, va, row0, nrows);
+  tile_commit(tb, vb, row0, nrows);
 }
 
 // fragment for rows [rbase, rbase+16): contraction group g
@@ -145,9 +169,15 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(AttnArgs a, float* __rest
   const float* kbase = a.k + (size_t)b * S * a.ldkv + h * HD;
   const float* vbase = a.v + (size_t)b * S * a.ldkv + h * HD;
 
-  stage_tile(Qs, qbase, q0, Sq, (size_t)a.ldq);
-  stage_tile(Ks, kbase, 0, S, (size_t)a.ldkv);
-  stage_tile(Vs, vbase, 0, S, (size_t)a.ldkv);
+  {
+    f32x4 vq[4], vk[4], vv[4];
+    tile_fetch(vq, qbase, q0, Sq, (size_t)a.ldq);
+    tile_fetch(vk, kbase, 0, S, (size_t)a.ldkv);
+    tile_fetch(vv, vbase, 0, S, (size_t)a.ldkv);
+    tile_commit(Qs, vq, q0, Sq);
+    tile_commit(Ks, vk, 0, S);
+    tile_commit(Vs, vv, 0, S);
+  }
   __syncthreads();
   f32x4 qf[4];
 #pragma unroll
@@ -167,8 +197,7 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(AttnArgs a, float* __rest
   for (int kt = 0; kt < nkt; ++kt) {
     if (kt > 0) {
       __syncthreads();  // everyone is done with the previous K/V tile
-      stage_tile(Ks, kbase, kt * TS, S, (size_t)a.ldkv);
-      stage_tile(Vs, vbase, kt * TS, S, (size_t)a.ldkv);
+      stage_tiles2(Ks, kbase, (size_t)a.ldkv, Vs, vbase, (size_t)a.ldkv, kt * TS, S);
       __syncthreads();
     }
     f32x4 s[4];
@@ -254,16 +283,26 @@ __global__ void __launch_bounds__(KT * 64) attn_fwd_rows_kernel(AttnArgs a, floa
 #pragma unroll
     for (int g = 0; g < 4; ++g) qf[g] = *reinterpret_cast<const f32x4*>(qrow + 16 * g);   // rows >= S: never stored
   }
+  // K and V of the head: R * 16 chunks over KT * 64 threads = 4 per thread and tensor, all eight loads requested before
+  // the first is waited for (rows past the end read row S-1 and are zeroed: see tile_fetch)
   const float* src[2] = {a.k + (size_t)b * S * a.ldkv + h * HD, a.v + (size_t)b * S * a.ldkv + h * HD};
+  {
+    f32x4 stg[2][4];
 #pragma unroll
-  for (int w = 0; w < 2; ++w) {
-    float* tile = lds_rows + w * R * HD;
-    for (int id = threadIdx.x; id < R * 16; id += KT * 64) {
-      const int row = id >> 4, slot = id & 15;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (row < S) v = *reinterpret_cast<const f32x4*>(src[w] + (size_t)row * a.ldkv + slot * 4);
-      *reinterpret_cast<f32x4*>(tile + row * HD + ((slot ^ (row & 15)) << 2)) = v;
-    }
+    for (int w = 0; w < 2; ++w)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int id = threadIdx.x + c * (KT * 64);
+        stg[w][c] = *reinterpret_cast<const f32x4*>(src[w] + (size_t)min(id >> 4, S - 1) * a.ldkv + (id & 15) * 4);
+      }
+#pragma unroll
+    for (int w = 0; w < 2; ++w)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int id = threadIdx.x + c * (KT * 64), row = id >> 4, slot = id & 15;
+        if (row >= S) stg[w][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        *reinterpret_cast<f32x4*>(lds_rows + w * R * HD + row * HD + ((slot ^ (row & 15)) << 2)) = stg[w][c];
+      }
   }
   __syncthreads();
   const int nkt = CAUSAL ? wave + 1 : (S + 15) / 16;  // wave-uniform
@@ -367,8 +406,7 @@ __global__ void __launch_bounds__(256) attn_fwd_stream_kernel(AttnArgs a, float*
   if (CAUSAL) nkt = min(nkt, (int)(blockIdx.y * 128 + 127) / TS + 1);
   for (int kt = 0; kt < nkt; ++kt) {
     if (kt > 0) __syncthreads();
-    stage_tile(Ks, kbase, kt * TS, S, (size_t)a.ldkv);
-    stage_tile(Vs, vbase, kt * TS, S, (size_t)a.ldkv);
+    stage_tiles2(Ks, kbase, (size_t)a.ldkv, Vs, vbase, (size_t)a.ldkv, kt * TS, S);
     __syncthreads();
     if (!wave_live || (CAUSAL && kt * TS > q0 + 31)) continue;
     // second 32-key half of the tile: skipped when it holds no key this wave needs (wave-uniform)
@@ -487,8 +525,7 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(AttnArgs a, const floa
       if (q0 + row < Sq) delta[(size_t)bh * Sq + q0 + row] = s;
     }
   }
-  stage_tile(t0, qbase, q0, Sq, (size_t)a.ldq);
-  stage_tile(t1, dobase, q0, Sq, (size_t)D);
+  stage_tiles2(t0, qbase, (size_t)a.ldq, t1, dobase, (size_t)D, q0, Sq);
   __syncthreads();
   f32x4 qf[4], dof[4];
 #pragma unroll
@@ -509,8 +546,7 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(AttnArgs a, const floa
   if (CAUSAL) nkt = min(nkt, (int)blockIdx.y + 1);
   for (int kt = 0; kt < nkt; ++kt) {
     __syncthreads();
-    stage_tile(t0, kbase, kt * TS, S, (size_t)a.ldkv);
-    stage_tile(t1, vbase, kt * TS, S, (size_t)a.ldkv);
+    stage_tiles2(t0, kbase, (size_t)a.ldkv, t1, vbase, (size_t)a.ldkv, kt * TS, S);
     __syncthreads();
     f32x4 s[4], dp[4];
     zero4(s);
@@ -564,8 +600,7 @@ __global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(AttnArgs a, const flo
   float* scp = scratch_p + wave * 16 * SCR;
   float* scs = scratch_s + wave * 16 * SCR;
 
-  stage_tile(t0, kbase, k0, S, (size_t)a.ldkv);
-  stage_tile(t1, vbase, k0, S, (size_t)a.ldkv);
+  stage_tiles2(t0, kbase, (size_t)a.ldkv, t1, vbase, (size_t)a.ldkv, k0, S);
   __syncthreads();
   f32x4 kf[4], vf[4];
 #pragma unroll
@@ -580,8 +615,7 @@ __global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(AttnArgs a, const flo
   for (int qt = CAUSAL ? (int)blockIdx.y : 0; qt < nqt; ++qt) {
     const int q0 = qt * TS;
     __syncthreads();
-    stage_tile(t0, qbase, q0, Sq, (size_t)a.ldq);
-    stage_tile(t1, dobase, q0, Sq, (size_t)D);
+    stage_tiles2(t0, qbase, (size_t)a.ldq, t1, dobase, (size_t)D, q0, Sq);
     if (threadIdx.x < TS) {
       const int q = q0 + threadIdx.x;
       lse_s[threadIdx.x] = (q < Sq) ? lse[(size_t)bh * Sq + q] : 0.f;
@@ -652,8 +686,11 @@ __global__ void __launch_bounds__(256, 3) attn_bwd_lean_kernel(AttnArgs a, const
   const float* kbase = a.k + (size_t)b * S * a.ldkv + h * HD;
   const float* vbase = a.v + (size_t)b * S * a.ldkv + h * HD;
   const float* dobase = dout + (size_t)b * S * D + h * HD;
-  stage_tile(Qs, qbase, 0, S, (size_t)a.ldq);
-  stage_tile(dOs, dobase, 0, S, (size_t)D);
+  f32x4 tq[4], tdo[4];                      // Q and dO tiles: requested here, written to LDS behind the fragment loads
+  tile_fetch(tq, qbase, 0, S, (size_t)a.ldq);
+  tile_fetch(tdo, dobase, 0, S, (size_t)D);
+  f32x4 tk[4];                              // phase B's K tile: requested with the rest, kept in registers through phase A
+  tile_fetch(tk, kbase, 0, S, (size_t)a.ldkv);
   const int own = 16 * wave + l15, ownc = min(own, S - 1);
   // own K / V rows as B-operand fragments: row own, head dims 16g + 4qd .. +3
   f32x4 kf[4], vf[4];
@@ -672,12 +709,18 @@ __global__ void __launch_bounds__(256, 3) attn_bwd_lean_kernel(AttnArgs a, const
       my_dl += (o4[0] * d4[0] + o4[1] * d4[1]) + (o4[2] * d4[2] + o4[3] * d4[3]);
     }
   }
+  const float my_lse = lse[(size_t)bh * S + ownc];
+  __builtin_amdgcn_sched_barrier(0);        // every load of the prologue is in flight before the first wait
+  tile_commit(Qs, tq, 0, S);
+  tile_commit(dOs, tdo, 0, S);
   my_dl += __shfl_xor(my_dl, 16);
   my_dl += __shfl_xor(my_dl, 32);
   if (qd == 0) {
-    lse_s[own] = own < S ? lse[(size_t)bh * S + own] : 0.f;
+    lse_s[own] = own < S ? my_lse : 0.f;
     dl_s[own] = own < S ? my_dl : 0.f;
   }
+#pragma unroll
+  for (int c = 0; c < 4; ++c) asm volatile("" ::"v"(tk[c]));   // (the optimizer would sink these loads to their use in phase B)
   __syncthreads();
   const int kts = (S + 15) / 16;
   // ---- phase A: own keys, every query tile -> dK, dV, and the dS tile
@@ -731,7 +774,7 @@ __global__ void __launch_bounds__(256, 3) attn_bwd_lean_kernel(AttnArgs a, const
     }
   }
   __syncthreads();                                   // Q tile dead, dS tile complete
-  stage_tile(Qs, kbase, 0, S, (size_t)a.ldkv);       // K over Q
+  tile_commit(Qs, tk, 0, S);                         // K over Q
   __syncthreads();
   // ---- phase B: own queries -> dQ^T = K^T dS^T
   {
@@ -810,8 +853,7 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_stream_kernel(AttnArgs a, con
   if (CAUSAL) nkt = min(nkt, (int)(blockIdx.y * 128 + 127) / TS + 1);
   for (int kt = 0; kt < nkt; ++kt) {
     if (kt > 0) __syncthreads();
-    stage_tile(Ks, kbase, kt * TS, S, (size_t)a.ldkv);
-    stage_tile(Vs, vbase, kt * TS, S, (size_t)a.ldkv);
+    stage_tiles2(Ks, kbase, (size_t)a.ldkv, Vs, vbase, (size_t)a.ldkv, kt * TS, S);
     __syncthreads();
     if (!wave_live || (CAUSAL && kt * TS > q0 + 31)) continue;
 #pragma unroll
@@ -906,8 +948,7 @@ __global__ void __launch_bounds__(256) attn_bwd_dkv_stream_kernel(AttnArgs a, co
   const int qt0 = CAUSAL ? (int)(blockIdx.y * 128) / TS : 0;   // queries before the workgroup's first key see none of its keys
   for (int qt = qt0; qt < nqt; ++qt) {
     if (qt > qt0) __syncthreads();
-    stage_tile(Qs, qbase, qt * TS, S, (size_t)a.ldq);
-    stage_tile(dOs, dobase, qt * TS, S, (size_t)D);
+    stage_tiles2(Qs, qbase, (size_t)a.ldq, dOs, dobase, (size_t)D, qt * TS, S);
     if (threadIdx.x < TS) {
       const int q = qt * TS + threadIdx.x;
       lse_s[threadIdx.x] = q < S ? lse[(size_t)bh * S + q] : 0.f;
@@ -998,10 +1039,8 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_fused_kernel(AttnArgs a, cons
   const float* obase = out + (size_t)b * S * D + h * HD;
   const float* dobase = dout + (size_t)b * S * D + h * HD;
 
-  stage_tile(Qs, qbase, 0, S, (size_t)a.ldq);
-  stage_tile(Ks, kbase, 0, S, (size_t)a.ldkv);
-  stage_tile(Vs, vbase, 0, S, (size_t)a.ldkv);
-  stage_tile(dOs, dobase, 0, S, (size_t)D);
+  stage_tiles2(Qs, qbase, (size_t)a.ldq, Ks, kbase, (size_t)a.ldkv, 0, S);
+  stage_tiles2(Vs, vbase, (size_t)a.ldkv, dOs, dobase, (size_t)D, 0, S);
   // delta and lse for this lane's 4 query rows (rows 16*wave + 4*qd + r): 16 lanes share a row -> each sums 4 floats
   float dl[4], lse_r[4];
 #pragma unroll
@@ -1092,14 +1131,23 @@ __global__ void __launch_bounds__(KT * 64) attn_bwd_rows_kernel(AttnArgs a, cons
                          a.v + (size_t)b * S * a.ldkv + h * HD, dout + (size_t)b * S * D + h * HD};
   const size_t lds_[4] = {(size_t)a.ldq, (size_t)a.ldkv, (size_t)a.ldkv, (size_t)D};
 #pragma unroll
-  for (int w = 0; w < 4; ++w) {
-    float* tile = lds + w * R * HD;
-    for (int id = threadIdx.x; id < R * 16; id += KT * 64) {
-      const int row = id >> 4, slot = id & 15;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (row < S) v = *reinterpret_cast<const f32x4*>(src[w] + (size_t)row * lds_[w] + slot * 4);
-      *reinterpret_cast<f32x4*>(tile + row * HD + ((slot ^ (row & 15)) << 2)) = v;
-    }
+  for (int w2 = 0; w2 < 4; w2 += 2) {            // two tensors (eight loads per thread) in flight at a time
+    f32x4 stg[2][4];
+#pragma unroll
+    for (int w = 0; w < 2; ++w)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int id = threadIdx.x + c * (KT * 64);
+        stg[w][c] = *reinterpret_cast<const f32x4*>(src[w2 + w] + (size_t)min(id >> 4, S - 1) * lds_[w2 + w] + (id & 15) * 4);
+      }
+#pragma unroll
+    for (int w = 0; w < 2; ++w)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int id = threadIdx.x + c * (KT * 64), row = id >> 4, slot = id & 15;
+        if (row >= S) stg[w][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        *reinterpret_cast<f32x4*>(lds + (w2 + w) * R * HD + row * HD + ((slot ^ (row & 15)) << 2)) = stg[w][c];
+      }
   }
   // delta = rowsum(O * dO) and lse of this wave's rows: lane (l15, qd) covers 16 of the 64 head dims of row 16w + l15
   const int own = 16 * wave + l15;
