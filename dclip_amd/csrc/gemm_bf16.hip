@@ -761,7 +761,7 @@ __global__ void __launch_bounds__(256) cast_bf16_kernel(const float* __restrict_
 }
 
 // LayerNorm with bf16 output (fp32 statistics and affine): one wave per row
-template <int NC>
+template <int NC, bool EXACT>   // EXACT: D == 256 NC, no per-chunk bounds tests; loads hoisted into one group (see layernorm.hip)
 __global__ void __launch_bounds__(256) ln_fwd_bf16_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, unsigned short* __restrict__ y,
                                                           int rows, int D, float eps, float* __restrict__ mean_out,
@@ -771,20 +771,25 @@ __global__ void __launch_bounds__(256) ln_fwd_bf16_kernel(const float* __restric
   if (row >= rows) return;
   const int d4 = D >> 2;
   const f32x4* xr = reinterpret_cast<const f32x4*>(x + (size_t)row * D);
-  f32x4 v[NC];
+  f32x4 v[NC], g[NC], bt[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const int i = lane + 64 * c, ic = (EXACT || i < d4) ? i : 0;
+    v[c] = xr[ic];
+    g[c] = reinterpret_cast<const f32x4*>(gamma)[ic];
+    bt[c] = reinterpret_cast<const f32x4*>(beta)[ic];
+  }
   float s = 0.f;
 #pragma unroll
   for (int c = 0; c < NC; ++c) {
-    int i = lane + 64 * c;
-    v[c] = (i < d4) ? xr[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+    if (!EXACT && lane + 64 * c >= d4) v[c] = f32x4{0.f, 0.f, 0.f, 0.f};
     s += (v[c][0] + v[c][1]) + (v[c][2] + v[c][3]);
   }
   const float mu = wave_sum(s) / (float)D;
   float q = 0.f;
 #pragma unroll
   for (int c = 0; c < NC; ++c) {
-    int i = lane + 64 * c;
-    if (i < d4) {
+    if (EXACT || lane + 64 * c < d4) {
       f32x4 d = v[c] - mu;
       q += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
     }
@@ -796,9 +801,9 @@ __global__ void __launch_bounds__(256) ln_fwd_bf16_kernel(const float* __restric
   }
 #pragma unroll
   for (int c = 0; c < NC; ++c) {
-    int i = lane + 64 * c;
-    if (i < d4) {
-      f32x4 o = (v[c] - mu) * rs * reinterpret_cast<const f32x4*>(gamma)[i] + reinterpret_cast<const f32x4*>(beta)[i];
+    const int i = lane + 64 * c;
+    if (EXACT || i < d4) {
+      f32x4 o = (v[c] - mu) * rs * g[c] + bt[c];
       u16x4 b = {f32_to_bf16_bits(o[0]), f32_to_bf16_bits(o[1]), f32_to_bf16_bits(o[2]), f32_to_bf16_bits(o[3])};
       *reinterpret_cast<u16x4*>(y + (size_t)row * D + i * 4) = b;
     }
@@ -891,12 +896,15 @@ DCLIP_API int dclip_layernorm_fwd_bf16_stats(const float* x, const float* gamma,
   hipStream_t st = (hipStream_t)stream;
   const int nc = cdiv(D / 4, 64);
   unsigned short* yy = (unsigned short*)y;
-#define LN16(NC) hipLaunchKernelGGL((ln_fwd_bf16_kernel<NC>), grid, block, 0, st, x, gamma, beta, yy, rows, D, eps, mean, rstd)
-  if (nc <= 1) LN16(1);
-  else if (nc == 2) LN16(2);
-  else if (nc == 3) LN16(3);
-  else if (nc == 4) LN16(4);
-  else LN16(8);
+#define LN16(NC, EX) hipLaunchKernelGGL((ln_fwd_bf16_kernel<NC, EX>), grid, block, 0, st, x, gamma, beta, yy, rows, D, eps, mean, rstd)
+  if (D == 512) LN16(2, true);
+  else if (D == 768) LN16(3, true);
+  else if (D == 1024) LN16(4, true);
+  else if (nc <= 1) LN16(1, false);
+  else if (nc == 2) LN16(2, false);
+  else if (nc == 3) LN16(3, false);
+  else if (nc == 4) LN16(4, false);
+  else LN16(8, false);
 #undef LN16
   DCLIP_CHECK_LAUNCH("layernorm_fwd_bf16");
   return DCLIP_OK;

@@ -8,7 +8,11 @@ namespace {
 
 constexpr int MAXC = 8;  // float4 chunks per lane -> D <= 2048
 
-template <int NC>
+// EXACT: D == 256 NC (every CLIP width: 512, 768, 1024) — the `i < d4` tests compile away.  Loads are written as one
+// unconditional group per row (x, gamma, beta / dy, x, dresidual: a lane past the row end re-reads chunk 0 and its
+// value is discarded): a load under a per-chunk condition is waited for on its own (vmcnt(0), which also waits for
+// every store issued before it), which made a row 4-7 serial round trips to memory.
+template <int NC, bool EXACT>
 __global__ void __launch_bounds__(256) ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, float* __restrict__ y,
                                                      float* __restrict__ mean, float* __restrict__ rstd, int rows,
@@ -18,20 +22,25 @@ __global__ void __launch_bounds__(256) ln_fwd_kernel(const float* __restrict__ x
   if (row >= rows) return;
   const int d4 = D >> 2;
   const f32x4* xr = reinterpret_cast<const f32x4*>(x + (size_t)row * D);
-  f32x4 v[NC];
+  f32x4 v[NC], g[NC], bt[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const int i = lane + 64 * c, ic = (EXACT || i < d4) ? i : 0;
+    v[c] = xr[ic];
+    g[c] = reinterpret_cast<const f32x4*>(gamma)[ic];
+    bt[c] = reinterpret_cast<const f32x4*>(beta)[ic];
+  }
   float s = 0.f;
 #pragma unroll
   for (int c = 0; c < NC; ++c) {
-    int i = lane + 64 * c;
-    v[c] = (i < d4) ? xr[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+    if (!EXACT && lane + 64 * c >= d4) v[c] = f32x4{0.f, 0.f, 0.f, 0.f};
     s += (v[c][0] + v[c][1]) + (v[c][2] + v[c][3]);
   }
   const float mu = wave_sum(s) / (float)D;
   float q = 0.f;
 #pragma unroll
   for (int c = 0; c < NC; ++c) {
-    int i = lane + 64 * c;
-    if (i < d4) {
+    if (EXACT || lane + 64 * c < d4) {
       f32x4 d = v[c] - mu;
       q += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
     }
@@ -44,18 +53,14 @@ __global__ void __launch_bounds__(256) ln_fwd_kernel(const float* __restrict__ x
   f32x4* yr = reinterpret_cast<f32x4*>(y + (size_t)row * D);
 #pragma unroll
   for (int c = 0; c < NC; ++c) {
-    int i = lane + 64 * c;
-    if (i < d4) {
-      f32x4 g = reinterpret_cast<const f32x4*>(gamma)[i];
-      f32x4 b = reinterpret_cast<const f32x4*>(beta)[i];
-      yr[i] = (v[c] - mu) * rs * g + b;
-    }
+    const int i = lane + 64 * c;
+    if (EXACT || i < d4) yr[i] = (v[c] - mu) * rs * g[c] + bt[c];
   }
 }
 
 // Each wave walks rows with a grid stride; per-column dgamma/dbeta partials stay in registers, are summed
 // over the block's 4 waves through LDS and written to partial[blockIdx][2][D].
-template <int NC>
+template <int NC, bool EXACT>
 __global__ void __launch_bounds__(256) ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, const float* __restrict__ dres,
@@ -68,23 +73,31 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const float* __restrict__ d
 #pragma unroll
   for (int c = 0; c < NC; ++c) {
     int i = lane + 64 * c;
-    g[c] = (i < d4) ? reinterpret_cast<const f32x4*>(gamma)[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+    g[c] = (EXACT || i < d4) ? reinterpret_cast<const f32x4*>(gamma)[i] : f32x4{0.f, 0.f, 0.f, 0.f};
     dg[c] = f32x4{0.f, 0.f, 0.f, 0.f};
     db[c] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
   const float invD = 1.0f / (float)D;
+  const bool has_res = dres != nullptr;                       // wave-uniform
   for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
     const f32x4* xr = reinterpret_cast<const f32x4*>(x + (size_t)row * D);
     const f32x4* dyr = reinterpret_cast<const f32x4*>(dy + (size_t)row * D);
+    const f32x4* rr = reinterpret_cast<const f32x4*>((has_res ? dres : dy) + (size_t)row * D);   // (a valid address either way)
     const float mu = mean[row], rs = rstd[row];
-    f32x4 xh[NC], dyh[NC];
+    f32x4 xh[NC], dyh[NC], rv[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const int i = lane + 64 * c, ic = (EXACT || i < d4) ? i : 0;
+      dyh[c] = dyr[ic];
+      xh[c] = xr[ic];
+      rv[c] = rr[ic];
+    }
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
-      int i = lane + 64 * c;
-      if (i < d4) {
-        f32x4 dyv = dyr[i];
-        xh[c] = (xr[i] - mu) * rs;
+      if (EXACT || lane + 64 * c < d4) {
+        const f32x4 dyv = dyh[c];
+        xh[c] = (xh[c] - mu) * rs;
         dg[c] += dyv * xh[c];
         db[c] += dyv;
         dyh[c] = dyv * g[c];
@@ -100,10 +113,10 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const float* __restrict__ d
     f32x4* dxr = reinterpret_cast<f32x4*>(dx + (size_t)row * D);
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
-      int i = lane + 64 * c;
-      if (i < d4) {
+      const int i = lane + 64 * c;
+      if (EXACT || i < d4) {
         f32x4 o = (dyh[c] - c2 - xh[c] * c1) * rs;
-        if (dres) o += reinterpret_cast<const f32x4*>(dres + (size_t)row * D)[i];
+        if (has_res) o += rv[c];
         dxr[i] = o;
       }
     }
@@ -112,7 +125,7 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const float* __restrict__ d
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
       int i = lane + 64 * c;
-      if (i < d4) {
+      if (EXACT || i < d4) {
         reinterpret_cast<f32x4*>(red + (wave * 2 + 0) * D)[i] = dg[c];
         reinterpret_cast<f32x4*>(red + (wave * 2 + 1) * D)[i] = db[c];
       }
@@ -199,12 +212,15 @@ DCLIP_API int dclip_layernorm_fwd(const float* x, const float* gamma, const floa
   dim3 grid(cdiv(rows, 4)), block(256);
   hipStream_t st = (hipStream_t)stream;
   const int nc = cdiv(D / 4, 64);
-#define LN_FWD(NC) hipLaunchKernelGGL((ln_fwd_kernel<NC>), grid, block, 0, st, x, gamma, beta, y, mean, rstd, rows, D, eps)
-  if (nc <= 1) LN_FWD(1);
-  else if (nc == 2) LN_FWD(2);
-  else if (nc == 3) LN_FWD(3);
-  else if (nc == 4) LN_FWD(4);
-  else LN_FWD(8);
+#define LN_FWD(NC, EX) hipLaunchKernelGGL((ln_fwd_kernel<NC, EX>), grid, block, 0, st, x, gamma, beta, y, mean, rstd, rows, D, eps)
+  if (D == 512) LN_FWD(2, true);            // the CLIP widths: no per-chunk bounds tests
+  else if (D == 768) LN_FWD(3, true);
+  else if (D == 1024) LN_FWD(4, true);
+  else if (nc <= 1) LN_FWD(1, false);
+  else if (nc == 2) LN_FWD(2, false);
+  else if (nc == 3) LN_FWD(3, false);
+  else if (nc == 4) LN_FWD(4, false);
+  else LN_FWD(8, false);
 #undef LN_FWD
   DCLIP_CHECK_LAUNCH("layernorm_fwd");
   return DCLIP_OK;
@@ -231,13 +247,16 @@ DCLIP_API int dclip_layernorm_bwd(const float* dy, const float* x, const float* 
   hipStream_t st = (hipStream_t)stream;
   const size_t lds = want_params ? (size_t)8 * D * sizeof(float) : 0;
   const int nc = cdiv(D / 4, 64);
-#define LN_BWD(NC) \
-  hipLaunchKernelGGL((ln_bwd_kernel<NC>), dim3(blocks), dim3(256), lds, st, dy, x, gamma, mean, rstd, dresidual, dx, partial, rows, D)
-  if (nc <= 1) LN_BWD(1);
-  else if (nc == 2) LN_BWD(2);
-  else if (nc == 3) LN_BWD(3);
-  else if (nc == 4) LN_BWD(4);
-  else LN_BWD(8);
+#define LN_BWD(NC, EX) \
+  hipLaunchKernelGGL((ln_bwd_kernel<NC, EX>), dim3(blocks), dim3(256), lds, st, dy, x, gamma, mean, rstd, dresidual, dx, partial, rows, D)
+  if (D == 512) LN_BWD(2, true);
+  else if (D == 768) LN_BWD(3, true);
+  else if (D == 1024) LN_BWD(4, true);
+  else if (nc <= 1) LN_BWD(1, false);
+  else if (nc == 2) LN_BWD(2, false);
+  else if (nc == 3) LN_BWD(3, false);
+  else if (nc == 4) LN_BWD(4, false);
+  else LN_BWD(8, false);
 #undef LN_BWD
   DCLIP_CHECK_LAUNCH("layernorm_bwd");
   if (want_params) {
