@@ -19,10 +19,12 @@ $(LIB): $(OBJS)
 # Diagnostic library with in-kernel time stamps in the GEMM (tools/gemm_stamps.py); never loaded by the product.
 STAMPLIB := tools/ab/libdclip_hip_stamps.so
 stamps: $(STAMPLIB)
-$(STAMPLIB): $(OBJS) $(CSRC)/gemm_f32.hip
+$(STAMPLIB): $(OBJS) $(CSRC)/gemm_f32.hip $(CSRC)/gemm_bf16.hip
 	@mkdir -p tools/ab
 	$(HIPCC) $(HIPFLAGS) -DDCLIP_GEMM_STAMPS -c $(CSRC)/gemm_f32.hip -o $(CSRC)/build/gemm_f32_stamps.o
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(filter-out $(CSRC)/build/gemm_f32.o,$(OBJS)) $(CSRC)/build/gemm_f32_stamps.o
+	$(HIPCC) $(HIPFLAGS) -DDCLIP_GEMM_STAMPS -c $(CSRC)/gemm_bf16.hip -o $(CSRC)/build/gemm_bf16_stamps.o
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(filter-out $(CSRC)/build/gemm_f32.o $(CSRC)/build/gemm_bf16.o,$(OBJS)) \
+		$(CSRC)/build/gemm_f32_stamps.o $(CSRC)/build/gemm_bf16_stamps.o
 
 clean:
 	rm -rf $(CSRC)/build $(LIB)

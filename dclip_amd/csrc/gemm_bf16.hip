@@ -48,6 +48,24 @@ __device__ __forceinline__ unsigned short f32_to_bf16_bits(float x) {
   return __builtin_bit_cast(unsigned short, b);
 }
 
+// Diagnostic build only (`make stamps`, never the product library): per-workgroup shader-clock stamps of the ping-pong
+// kernel (entry / K loop start / K loop end / first pass stored / exit; real-time clock at entry and exit; where it ran) into
+// a buffer of their own.  tools/bf16_gemm_stamps.py.
+#ifdef DCLIP_GEMM_STAMPS
+__device__ unsigned long long* g_stamps16 = nullptr;
+#define PP_STAMP_V(slot, value)                                                                  \
+  do {                                                                                           \
+    if (threadIdx.x == 0 && g_stamps16)                                                          \
+      g_stamps16[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 16 + (slot)] = (value);         \
+  } while (0)
+#define PP_STAMP(slot) PP_STAMP_V(slot, __builtin_amdgcn_s_memtime())
+#define PP_STAMP_RT(slot) PP_STAMP_V(slot, __builtin_amdgcn_s_memrealtime())
+#else
+#define PP_STAMP_V(slot, value) do {} while (0)
+#define PP_STAMP(slot) do {} while (0)
+#define PP_STAMP_RT(slot) do {} while (0)
+#endif
+
 __device__ __forceinline__ int xcd_remap16(int bid, int nwg) {
   int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, i = bid >> 3;
   int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
@@ -519,8 +537,15 @@ __device__ __forceinline__ void pp_epilogue(const GemmBf16Params& p, const f32x4
     if (hm == 0) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // pass 0's LDS reads are done before pass 1 overwrites them
       PP_BARRIER();
+      PP_STAMP(3);             // first pass: stores issued
     }
   }
+  PP_STAMP(8);                 // second pass: stores issued
+#ifdef DCLIP_GEMM_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+  PP_STAMP(4);                 // ... and acknowledged (diagnostic build only: the product kernel ends without waiting)
+  PP_STAMP_RT(6);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -549,6 +574,10 @@ __global__ void __launch_bounds__(512) gemm_bf16_pp_kernel(GemmBf16Params p) {
   __shared__ __attribute__((aligned(16))) unsigned char lds_raw[2 * BUF * 2];   // 128 KiB: the ONLY LDS object
   __bf16* lds = reinterpret_cast<__bf16*>(lds_raw);
 
+  PP_STAMP(0);
+  PP_STAMP_RT(5);
+  PP_STAMP_V(7, (unsigned long long)__builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11)) |
+                    ((unsigned long long)__builtin_amdgcn_s_getreg((20) | (0 << 6) | (3 << 11)) << 32));   // HW_ID, XCC_ID
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3;
@@ -650,6 +679,7 @@ __global__ void __launch_bounds__(512) gemm_bf16_pp_kernel(GemmBf16Params p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   PP_BARRIER();
+  PP_STAMP(1);                 // first K-tile landed
   if (wr == 1) PP_BARRIER();   // wave row 1 runs one barrier behind wave row 0
 
   for (int kt = 0; kt < nk; ++kt) {
@@ -697,6 +727,7 @@ __global__ void __launch_bounds__(512) gemm_bf16_pp_kernel(GemmBf16Params p) {
     PP_BARRIER();
   }
   if (wr == 0) PP_BARRIER();   // balance the stagger: everybody is past its last MFMA phase and LDS read
+  PP_STAMP(2);                 // K loop done
 #undef PP_ISSUE_A
 #undef PP_ISSUE_B
 #undef PP_READ_A
@@ -828,6 +859,13 @@ inline int grid_for(size_t work) {
 }
 
 }  // namespace
+
+#ifdef DCLIP_GEMM_STAMPS
+// [workgroups][16] uint64 on the device, or nullptr to stop stamping (diagnostic library only)
+DCLIP_API int dclip_debug_set_bf16_stamps(void* buf) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_stamps16), &buf, sizeof(buf)) == hipSuccess ? DCLIP_OK : DCLIP_ELAUNCH;
+}
+#endif
 
 DCLIP_API int dclip_gemm_bf16(const void* A, const void* W, void* C, const float* bias, const float* residual, int M, int N,
                               int K, int lda, int ldw, int ldc, int epilogue, int out_bf16, void* stream) {
