@@ -471,6 +471,8 @@ int launch_dma(GemmBf16Params p, hipStream_t st) {
 // clamped addresses — BEFORE that pass's stores: vmcnt counts loads and stores together in issue order, so a load
 // issued behind stores waits for every one of them, and a load under a per-element condition is waited for alone.
 // KIND 0 bias only, 1 quick-GELU (pre-activation saved to aux when given), 2 x dGELU(aux), 3 + residual.
+// The MFMAs form C^T blocks (W fragment as the A operand): accumulator register r of block (i, j) is
+// C[row 16 i + l15][column 16 j + 4 quad + r] — four consecutive columns per lane, one ds_write_b128 per block.
 template <int KIND, bool OUT16>
 __device__ __forceinline__ void pp_epilogue(const GemmBf16Params& p, const f32x4 (&acc)[8][4], float* ct, int m0, int n0,
                                             int tid, int wr, int wc, int quad, int l15) {
@@ -495,20 +497,19 @@ __device__ __forceinline__ void pp_epilogue(const GemmBf16Params& p, const f32x4
       for (int q = 0; q < 16; ++q)
         side16[q] = *reinterpret_cast<const u16x4*>(p.aux + (size_t)min(rbase + 8 * q, p.M - 1) * p.ldc + colc);
     }
-    if (wr == hm) {
+    if (wr == hm) {      // 16-byte granule g of row r is stored at g ^ (r & 7): the 8 rows of a ds_write_b128 lane group spread over 32 banks
 #pragma unroll
       for (int i = 0; i < 8; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) ct[(16 * i + 4 * quad + r) * BN + 64 * wc + 16 * j + l15] = acc[i][j][r];
+          *reinterpret_cast<f32x4*>(ct + (16 * i + l15) * BN + (((16 * wc + 4 * j + quad) ^ (l15 & 7)) << 2)) = acc[i][j];
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     PP_BARRIER();
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
       const int row = rbase + 8 * q;
-      f32x4 v = *reinterpret_cast<const f32x4*>(ct + (lr0 + 8 * q) * BN + lc) + bias4;
+      f32x4 v = *reinterpret_cast<const f32x4*>(ct + (lr0 + 8 * q) * BN + (((tid & 63) ^ ((lr0 + 8 * q) & 7)) << 2)) + bias4;
       const size_t off = (size_t)row * p.ldc + col;
       const bool ok = row < p.M && colok;
       if (KIND == 1) {
@@ -545,6 +546,71 @@ __device__ __forceinline__ void pp_epilogue(const GemmBf16Params& p, const f32x4
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
   PP_STAMP(4);                 // ... and acknowledged (diagnostic build only: the product kernel ends without waiting)
+  PP_STAMP_RT(6);
+}
+
+// bf16 outputs without a side operand (qkv projection, fc1 + GELU): bias (and GELU, unless the pre-activation is to be
+// saved) are applied in registers, the values are rounded to bf16 THERE, and the whole 256 x 256 tile (128 KiB as bf16)
+// is staged at once — both wave rows write together (32 ds_write_b64 per wave instead of 128 ds_write_b32), one barrier
+// instead of three, and the copy loop moves 16 bytes per lane: 16 LDS reads pairs + 16 stores per thread for the tile.
+// 8-byte unit u of row r is stored at u ^ (r & 15): the 16 rows of a ds_write_b64 lane group cover 32 banks.
+// SAVE: the staged value is the pre-activation h (written to aux); C = bf16(gelu(h)) is formed in the copy loop from the
+// rounded h, as in the two-pass form.
+template <bool GELU, bool SAVE>
+__device__ __forceinline__ void pp_epilogue_b16(const GemmBf16Params& p, const f32x4 (&acc)[8][4], unsigned short* ct, int m0,
+                                                int n0, int tid, int wr, int wc, int quad, int l15) {
+  constexpr int BN = 256;
+  {
+    f32x4 bias4[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int col = n0 + 64 * wc + 16 * j + 4 * quad;
+      bias4[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (p.epilogue & DCLIP_EPI_BIAS) bias4[j] = *reinterpret_cast<const f32x4*>(p.bias + (col < p.N ? col : 0));
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        f32x4 v = acc[i][j] + bias4[j];
+        if (GELU && !SAVE) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = quick_gelu_f(v[e]);
+        }
+        const u16x4 h = {f32_to_bf16_bits(v[0]), f32_to_bf16_bits(v[1]), f32_to_bf16_bits(v[2]), f32_to_bf16_bits(v[3])};
+        const int row = 128 * wr + 16 * i + l15, unit = 16 * wc + 4 * j + quad;
+        *reinterpret_cast<u16x4*>(ct + row * BN + ((unit ^ (row & 15)) << 2)) = h;
+      }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  PP_BARRIER();
+  PP_STAMP(3);
+  const int cg = tid & 31, col = n0 + 8 * cg;       // 8 columns = two 8-byte units per thread and row
+#pragma unroll 4
+  for (int q = 0; q < 16; ++q) {
+    const int lr = (tid >> 5) + 16 * q, row = m0 + lr;
+    const u16x4 lo = *reinterpret_cast<const u16x4*>(ct + lr * BN + (((2 * cg) ^ (lr & 15)) << 2));
+    const u16x4 hi = *reinterpret_cast<const u16x4*>(ct + lr * BN + (((2 * cg + 1) ^ (lr & 15)) << 2));
+    if (row >= p.M || col >= p.N) continue;
+    const size_t off = (size_t)row * p.ldc + col;
+    const bool full = col + 8 <= p.N;               // N % 4 == 0: the second unit is inside or outside as a whole
+    typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+    u16x8 o = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    if (SAVE) {
+      if (full) *reinterpret_cast<u16x8*>(p.aux + off) = o;
+      else *reinterpret_cast<u16x4*>(p.aux + off) = lo;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = f32_to_bf16_bits(quick_gelu_f(__builtin_bit_cast(float, (unsigned int)o[e] << 16)));
+    }
+    unsigned short* c = reinterpret_cast<unsigned short*>(p.C) + off;
+    if (full) *reinterpret_cast<u16x8*>(c) = o;
+    else *reinterpret_cast<u16x4*>(c) = u16x4{o[0], o[1], o[2], o[3]};
+  }
+  PP_STAMP(8);
+#ifdef DCLIP_GEMM_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+  PP_STAMP(4);
   PP_STAMP_RT(6);
 }
 
@@ -661,7 +727,7 @@ __global__ void __launch_bounds__(512) gemm_bf16_pp_kernel(GemmBf16Params p) {
     _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                   \
     _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                   \
       acc[4 * (qm) + i][2 * (qn) + j] =                                                                             \
-          __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][s], fb[j][s], acc[4 * (qm) + i][2 * (qn) + j], 0, 0, 0);    \
+          __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j][s], fa[i][s], acc[4 * (qm) + i][2 * (qn) + j], 0, 0, 0);    \
     __builtin_amdgcn_s_setprio(0);                                                                                  \
   } while (0)
 
@@ -746,8 +812,10 @@ __global__ void __launch_bounds__(512) gemm_bf16_pp_kernel(GemmBf16Params p) {
     return;
   }
   if (p.out_bf16) {
-    if (kind == 0) pp_epilogue<0, true>(p, acc, ct, m0, n0, tid, wr, wc, quad, l15);
-    else if (kind == 1) pp_epilogue<1, true>(p, acc, ct, m0, n0, tid, wr, wc, quad, l15);
+    unsigned short* ct16 = reinterpret_cast<unsigned short*>(lds_raw);
+    if (kind == 0) pp_epilogue_b16<false, false>(p, acc, ct16, m0, n0, tid, wr, wc, quad, l15);
+    else if (kind == 1 && p.aux) pp_epilogue_b16<true, true>(p, acc, ct16, m0, n0, tid, wr, wc, quad, l15);
+    else if (kind == 1) pp_epilogue_b16<true, false>(p, acc, ct16, m0, n0, tid, wr, wc, quad, l15);
     else pp_epilogue<2, true>(p, acc, ct, m0, n0, tid, wr, wc, quad, l15);          // RESIDUAL needs an fp32 output (host check)
   } else {
     if (kind == 0) pp_epilogue<0, false>(p, acc, ct, m0, n0, tid, wr, wc, quad, l15);
