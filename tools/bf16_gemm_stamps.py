@@ -73,5 +73,16 @@ for name, M, N, K, kind in SHAPES:
           f"(MFMA peak at that clock {2500 * clk / 2.4:5.0f} TF/s) | {nwg} WGs, {nwg / 256:.2f}/CU (CUs seen {len(cus)}, max {per_cu.max()})", flush=True)
     print(f"    cycles median (p10..p90): prologue {q(t1 - t0)} | K loop {q(t2 - t1)} = {np.median(t2 - t1) / nk:6.0f}/K-tile (floor 2048) | "
           f"epilogue pass 1 {q(t3 - t2)} | pass 2 {q(t8 - t3)} | store ack {q(t4 - t8)} | whole {q(t4 - t0)}")
+    # how many workgroups are in their epilogue at the same time?  (epilogue interval on the real-time clock, from the
+    # cycle stamps' share of the workgroup's life)
+    life = np.maximum(t4 - t0, 1).astype(np.float64)
+    e_beg = r0 + (t2 - t0) / life * (r1 - r0)
+    e_end = r0 + (t8 - t0) / life * (r1 - r0)
+    grid = np.linspace(r0.min(), r1.max(), 2000)
+    conc = np.array([np.count_nonzero((e_beg <= g) & (g < e_end)) for g in grid])
+    running = np.array([np.count_nonzero((r0 <= g) & (g < r1)) for g in grid])
+    mid = slice(200, 1800)
+    print(f"    workgroups in their epilogue at the same time (middle 80 % of the span): mean {conc[mid].mean():5.1f} of {running[mid].mean():5.1f} running, "
+          f"p10 {np.percentile(conc[mid], 10):4.0f} p90 {np.percentile(conc[mid], 90):4.0f} max {conc[mid].max()}")
     print(f"    CU idle inside span: median {np.median(idle):6.1f} us max {idle.max():6.1f} us mean {idle.mean():6.1f} us ({idle.mean() / span_us * 100:4.1f} %)", flush=True)
     del a, w, out, res
