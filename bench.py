@@ -526,7 +526,7 @@ def main():
         g16 = timer.summary(bf16=True) if not args.no_gemm_events else (0.0, 0.0, 0)
         if g16[2] and graphed is None:
             # bf16 GEMM family (frozen teacher towers, bf16 student): its own roofline against the dense bf16 MFMA peak
-            line["roofline_bf16"] = {"bound": "mfma", "kernel": "gemm_bf16_dma_kernel / gemm_bf16_kernel (v_mfma_f32_32x32x16_bf16)",
+            line["roofline_bf16"] = {"bound": "mfma", "kernel": "gemm_bf16_pp_kernel (v_mfma_f32_16x16x32_bf16) / gemm_bf16_kernel (v_mfma_f32_32x32x16_bf16)",
                                      "achieved": round(g16[0] / (g16[1] * 1e-3) / 1e12, 2), "peak": 2500.0, "unit": "TFLOP/s",
                                      "frac": round(g16[0] / (g16[1] * 1e-3) / 1e12 / 2500.0, 4),
                                      "launches_per_step": g16[2] // n_ev,
