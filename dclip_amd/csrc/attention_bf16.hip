@@ -179,11 +179,20 @@ __global__ void __launch_bounds__(128) attn_fwd_bf16_kernel(const unsigned short
 // the accumulator and no running statistics — the online form's VALU work (rescale, alpha, masked selects on every
 // block) was twice its MFMA work at head dim 64.  Only the block that holds the sequence end (and, causal, the
 // diagonal block) runs the masked variant.
-template <int NB, bool CAUSAL>
-__global__ void __launch_bounds__(64 * NB) attn_fwd_bf16_head_kernel(const unsigned short* __restrict__ qkv,
+// XQ (S == 32 NB + 1, not causal: the 257 tokens of ViT-L/14): NB waves own the first 32 NB queries and SHARE the last one —
+// a ninth wave for one query makes the workgroup 9 waves, of which only one fits a CU at this register count (16 wave slots
+// at 4 per SIMD); with 8 waves two fit.  Wave w forms the last query's scores against key block w (wave 0 also the block
+// that holds the last key) with that query in every column of the B operand, its local maximum / sum / P V go to LDS, and
+// after one barrier wave 0 merges the NB + 1 partial results (the flash-attention merge, once per head).
+template <int NB, bool CAUSAL, bool XQ>
+__global__ void __launch_bounds__(64 * NB, (XQ ? 4 : 1)) attn_fwd_bf16_head_kernel(const unsigned short* __restrict__ qkv,
                                                                      unsigned short* __restrict__ out, int S, int H) {
-  __shared__ __attribute__((aligned(16))) unsigned char Ks[NB * 32 * 128];
-  __shared__ __attribute__((aligned(16))) unsigned char Vs[NB * 32 * 128];
+  constexpr int KB = NB + (XQ ? 1 : 0);            // 32-key blocks staged
+  constexpr int CHUNKS = KB * 256, NTHR = 64 * NB, ITER = (CHUNKS + NTHR - 1) / NTHR;
+  __shared__ __attribute__((aligned(16))) unsigned char Ks[KB * 32 * 128];
+  __shared__ __attribute__((aligned(16))) unsigned char Vs[KB * 32 * 128];
+  __shared__ __attribute__((aligned(16))) float xpart[XQ ? KB * 68 : 4];      // per key block: max, sum, pad, pad, O[64]
+  __shared__ __attribute__((aligned(16))) unsigned short xq_row[XQ ? 64 : 8];  // the shared query
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, half = lane >> 5;
@@ -204,20 +213,24 @@ __global__ void __launch_bounds__(64 * NB) attn_fwd_bf16_head_kernel(const unsig
   // all eight 16-byte loads of a thread go out together (rows past the end read the last row and are zeroed after: a
   // load under a per-row condition is waited for on its own — four serial round trips to memory per workgroup)
   {
-    u32x4 kv[4], vv[4];
+    u32x4 kv[ITER], vv[ITER], xqv = {0u, 0u, 0u, 0u};
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const int id = tid + c * (64 * NB), rc = min(id >> 3, S - 1), g = id & 7;
+    for (int c = 0; c < ITER; ++c) {
+      const int id = tid + c * NTHR, rc = min(id >> 3, S - 1), g = id & 7;
       kv[c] = *reinterpret_cast<const u32x4*>(base + (size_t)rc * ld + D + g * 8);
       vv[c] = *reinterpret_cast<const u32x4*>(base + (size_t)rc * ld + 2 * D + g * 8);
     }
+    if (XQ && tid < 8) xqv = *reinterpret_cast<const u32x4*>(base + (size_t)(S - 1) * ld + tid * 8);
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const int id = tid + c * (64 * NB), row = id >> 3, g = id & 7;
+    for (int c = 0; c < ITER; ++c) {
+      const int id = tid + c * NTHR, row = id >> 3, g = id & 7;
       if (row >= S) kv[c] = vv[c] = u32x4{0u, 0u, 0u, 0u};
-      *reinterpret_cast<u32x4*>(Ks + gran_off(row, g)) = kv[c];
-      *reinterpret_cast<u32x4*>(Vs + gran_off(row, g)) = vv[c];
+      if (CHUNKS % NTHR == 0 || id < CHUNKS) {
+        *reinterpret_cast<u32x4*>(Ks + gran_off(row, g)) = kv[c];
+        *reinterpret_cast<u32x4*>(Vs + gran_off(row, g)) = vv[c];
+      }
     }
+    if (XQ && tid < 8) *reinterpret_cast<u32x4*>(xq_row + tid * 8) = xqv;
   }
 #pragma unroll
   for (int s = 0; s < 4; ++s) asm volatile("" ::"v"(qf[s]));   // keep the Q loads in front of the barrier (the optimizer sinks them)
@@ -236,14 +249,15 @@ __global__ void __launch_bounds__(64 * NB) attn_fwd_bf16_head_kernel(const unsig
     for (int s = 0; s < 4; ++s)
       kf[s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(Ks + gran_off(32 * kb + l31, 2 * s + half)));
   };
-  auto qk = [&]() {
+  auto qk_with = [&](const bf16x8 (&q)[4]) {
     f32x16 st;
 #pragma unroll
     for (int r = 0; r < 16; ++r) st[r] = 0.f;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[s], qf[s], st, 0, 0, 0);
+    for (int s = 0; s < 4; ++s) st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[s], q[s], st, 0, 0, 0);
     return st;
   };
+  auto qk = [&]() { return qk_with(qf); };
   auto valid = [&](int kb, int r) {
     const int key = 32 * kb + (r & 3) + 8 * (r >> 2) + 4 * half;
     return key < S && (!CAUSAL || key <= query);
@@ -350,12 +364,69 @@ __global__ void __launch_bounds__(64 * NB) attn_fwd_bf16_head_kernel(const unsig
         *reinterpret_cast<u16x4*>(orow + 32 * dt + 8 * j + 4 * half) = v;
       }
   }
+  if (XQ) {
+    // ---- the shared last query: this wave's key block(s), that query in every column of the B operand
+    bf16x8 qx[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) qx[s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(xq_row + 16 * s + 8 * half));
+    const int nx = wave == 0 ? 2 : 1;
+    for (int x = 0; x < nx; ++x) {
+      const int xb = x == 0 ? wave : NB;             // wave 0 also takes the block with the last key
+      load_k(xb);
+      f32x16 st = qk_with(qx);
+      load_v(xb);
+      float m2 = -INFINITY;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = 32 * xb + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (key >= S) st[r] = -INFINITY;
+        m2 = fmaxf(m2, st[r]);
+      }
+      m2 = fmaxf(m2, __shfl_xor(m2, 32));            // every block holds at least one key: finite
+      float l2 = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        st[r] = __builtin_amdgcn_exp2f((st[r] - m2) * c);   // -inf -> 0
+        l2 += st[r];
+      }
+      l2 += __shfl_xor(l2, 32);
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+      pv(st);
+      if (l31 == 0) {                                // all 32 columns are the same query: column 0 writes
+        if (half == 0) {
+          xpart[xb * 68 + 0] = m2;
+          xpart[xb * 68 + 1] = l2;
+        }
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) xpart[xb * 68 + 4 + 32 * dt + (r & 3) + 8 * (r >> 2) + 4 * half] = o[dt][r];
+      }
+    }
+    __syncthreads();
+    if (wave == 0) {                                 // merge: lane d owns head dim d
+      float mm = -INFINITY;
+#pragma unroll
+      for (int xb = 0; xb < KB; ++xb) mm = fmaxf(mm, xpart[xb * 68]);
+      float num = 0.f, den = 0.f;
+#pragma unroll
+      for (int xb = 0; xb < KB; ++xb) {
+        const float w = __builtin_amdgcn_exp2f((xpart[xb * 68] - mm) * c);
+        den += w * xpart[xb * 68 + 1];
+        num += w * xpart[xb * 68 + 4 + lane];
+      }
+      out[((size_t)b * S + (S - 1)) * D + h * HD + lane] = bf16_bits(num / den);
+    }
+  }
 }
 
 template <int NB>
 void launch_head(const unsigned short* qkv, unsigned short* out, int B, int S, int H, int causal, hipStream_t st) {
-  if (causal) hipLaunchKernelGGL((attn_fwd_bf16_head_kernel<NB, true>), dim3(B * H), dim3(64 * NB), 0, st, qkv, out, S, H);
-  else hipLaunchKernelGGL((attn_fwd_bf16_head_kernel<NB, false>), dim3(B * H), dim3(64 * NB), 0, st, qkv, out, S, H);
+  if (causal) hipLaunchKernelGGL((attn_fwd_bf16_head_kernel<NB, true, false>), dim3(B * H), dim3(64 * NB), 0, st, qkv, out, S, H);
+  else hipLaunchKernelGGL((attn_fwd_bf16_head_kernel<NB, false, false>), dim3(B * H), dim3(64 * NB), 0, st, qkv, out, S, H);
 }
 
 }  // namespace
@@ -369,6 +440,12 @@ DCLIP_API int dclip_attention_fwd_bf16(const void* qkv, void* out, int B, int S,
   if (S <= 288 && !tiled_only) {                    // whole-head kernel: every CLIP tower (50 / 77 / 197 / 257 tokens)
     const unsigned short* q = (const unsigned short*)qkv;
     unsigned short* o = (unsigned short*)out;
+    static const bool no_xq = getenv("DCLIP_ATTN16_NO_XQ") && atoi(getenv("DCLIP_ATTN16_NO_XQ")) != 0;   // A/B switch
+    if (S == 257 && !causal && !no_xq) {            // 8 waves sharing the 257th query: two workgroups per CU instead of one
+      hipLaunchKernelGGL((attn_fwd_bf16_head_kernel<8, false, true>), dim3(B * H), dim3(512), 0, st, q, o, S, H);
+      DCLIP_CHECK_LAUNCH("attention_fwd_bf16.head_xq");
+      return DCLIP_OK;
+    }
     switch (cdiv(S, 32)) {
       case 1: launch_head<1>(q, o, B, S, H, causal, st); break;
       case 2: launch_head<2>(q, o, B, S, H, causal, st); break;

@@ -164,7 +164,7 @@ def test_gemm_bf16_big_tile_kernel_matches(pingpong):
 @pytest.mark.parametrize("B,S,H,causal", [(2, 50, 2, False), (2, 77, 2, True), (1, 257, 2, False), (1, 197, 1, False),
                                           (3, 64, 1, True), (2, 1, 1, False), (1, 130, 2, True), (2, 33, 3, False),
                                           (2, 288, 1, False), (1, 288, 2, True), (1, 289, 1, False), (2, 32, 2, True),
-                                          (1, 320, 2, True), (3, 96, 2, False)])     # <= 288: whole-head kernel, beyond: tiled
+                                          (1, 320, 2, True), (3, 96, 2, False), (3, 257, 3, False), (2, 257, 2, True)])     # <= 288: whole-head kernel (257: shared last query), beyond: tiled
 def test_attention_fwd_bf16(B, S, H, causal):
     """bf16 q/k/v, fp32 softmax, bf16 P and output: against an fp64 attention of the same rounded inputs."""
     from dclip_amd import ops
