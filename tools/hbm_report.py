@@ -11,9 +11,9 @@ rows_v, rows_t = B * S, B * T
 F = 4
 trainable = 87_456_000 + 393_216 + 1              # vision tower + visual_projection + logit_scale (north_star regime)
 KERNELS = {
-    "ln_fwd_kernel<3>": ("LayerNorm fwd, vision rows (x read, y written, 8 B/elem)", 2 * rows_v * D * F),
-    "ln_fwd_kernel<2>": ("LayerNorm fwd, text rows", 2 * rows_t * Dt * F),
-    "ln_bwd_kernel<3>": ("LayerNorm bwd + residual-gradient add (dy, x, dres read; dx written, 16 B/elem)", 4 * rows_v * D * F),
+    "ln_fwd_kernel<3, true>": ("LayerNorm fwd, vision rows (x read, y written, 8 B/elem)", 2 * rows_v * D * F),
+    "ln_fwd_kernel<2, true>": ("LayerNorm fwd, text rows", 2 * rows_t * Dt * F),
+    "ln_bwd_kernel<3, true>": ("LayerNorm bwd + residual-gradient add (dy, x, dres read; dx written, 16 B/elem)", 4 * rows_v * D * F),
     "attn_fwd_rows_kernel<4, false>": ("vision attention fwd (q,k,v read once, out written)", 4 * rows_v * D * F),
     "attn_fwd_rows_kernel<5, true>": ("text causal attention fwd", 4 * rows_t * Dt * F),
     "attn_bwd_lean_kernel<false>": ("vision attention bwd (q,k,v,o,do read; dq,dk,dv written)", 8 * rows_v * D * F),

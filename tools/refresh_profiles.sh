@@ -16,10 +16,10 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -o f -- python3 bench
 echo "fetch done"
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -o w -- python3 bench.py $B --steps 2 --warmup 1 > $O/write.log 2>&1
 echo "write done"
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/c3 -o s -- python3 bench.py $B --workload c3 --tower-precision bf16 --steps 4 --warmup 1 > $O/c3.log 2>&1
-echo "c3 done"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/c3b -o s -- python3 bench.py $B --workload c3 --tower-precision bf16 --student-precision bf16 --steps 4 --warmup 1 > $O/c3b.log 2>&1
 echo "c3 bf16 student done"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/c5b -o s -- python3 bench.py $B --workload c5 --batch 64 --tower-precision bf16 --student-precision bf16 --steps 4 --warmup 1 > $O/c5b.log 2>&1
+echo "c5 bf16 student done"
 python3 bench.py --workload c3 --tower-precision bf16 --no-cpu-baseline > $O/bench_c3.json 2> $O/bench_c3.err
 python3 bench.py --workload c3 --tower-precision bf16 --student-precision bf16 --no-cpu-baseline > $O/bench_c3_bf16_student.json 2> $O/bench_c3b.err
 python3 bench.py --workload c5 --batch 64 --steps 6 --warmup 2 --no-cpu-baseline > $O/bench_c5_b64.json 2> $O/bench_c5.err
