@@ -114,5 +114,21 @@ for name, layout, m, n, k in SHAPES[args.shapes]:
     print(f"    CUs seen {len(cus)}  WGs/CU min {per_cu.min()} max {per_cu.max()}  CU idle inside span: "
           f"median {np.median(idle):6.1f} us  p90 {np.percentile(idle, 90):6.1f} us  max {idle.max():6.1f} us  "
           f"mean {idle.mean():6.1f} us ({idle.mean() / span_us * 100:4.1f}% of span)")
+    # per CU: how many of its resident workgroups are inside their K loop at a time?  (K-loop interval on the real-time
+    # clock from the cycle stamps' share of the workgroup's life)  0 in the K loop = matrix pipes idle on that CU.
+    life = np.maximum(t3 - t0, 1).astype(np.float64)
+    k_beg = r0 + (t1 - t0) / life * (r1 - r0)
+    k_end = r0 + (t2 - t0) / life * (r1 - r0)
+    lo, hi = r0.min(), r1.max()
+    grid = np.linspace(lo + 0.1 * (hi - lo), lo + 0.9 * (hi - lo), 400)
+    hist = np.zeros(8)
+    for c in cus:
+        sel = cu_key == c
+        kb, ke = k_beg[sel], k_end[sel]
+        n = ((kb[None, :] <= grid[:, None]) & (grid[:, None] < ke[None, :])).sum(axis=1)
+        hist += np.bincount(np.minimum(n, 7), minlength=8)
+    hist /= hist.sum()
+    print("    workgroups of a CU inside their K loop (middle 80 % of the span): " +
+          "  ".join(f"{k}: {hist[k] * 100:4.1f} %" for k in range(5)) + f"   mean {sum(k * hist[k] for k in range(8)):.2f}")
     # concurrency-weighted efficiency: MFMA floor of all work on a CU / time the CU had at least one WG
     del a, b, out
