@@ -138,7 +138,10 @@ __global__ void __launch_bounds__(256) mt_adamw_kernel(const TensorRef* __restri
   for (size_t i = beg + (size_t)threadIdx.x * 4; i < e4; i += 1024) {
     f32x4 pv = *reinterpret_cast<f32x4*>(t.p + i);
     f32x4 gv = *reinterpret_cast<const f32x4*>(t.g + i) * gs;
-    if (COUPLED) gv = gv + pv * wd;
+    if (COUPLED) {     // g + wd p as ONE fused multiply-add of the (already scaled) gradient, as torch's add(param, alpha=wd):
+#pragma unroll          // where g ~ -wd p cancels, the other contraction a compiler may pick (fma(g, scale, wd p)) differs visibly
+      for (int e = 0; e < 4; ++e) gv[e] = __builtin_fmaf(pv[e], wd, gv[e]);
+    }
     f32x4 mv = *reinterpret_cast<f32x4*>(t.m + i);
     f32x4 vv = *reinterpret_cast<f32x4*>(t.v + i);
     mv = mv * beta1 + gv * (1.0f - beta1);
