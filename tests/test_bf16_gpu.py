@@ -213,3 +213,14 @@ def test_bf16_weight_cache_follows_the_fused_optimizer():
         after32 = m.get_image_features(pixel_values=pix)
     assert float((after16 - before).abs().max()) > 1e-3                      # the update is visible on the bf16 path
     assert float((after16 - after32).abs().max() / after32.abs().max()) < 3e-2
+
+
+def test_pingpong_gemm_repeat_launches_are_bit_identical():
+    """Race screen of the counted-vmcnt / raw-barrier schedule (tools/bf16_gemm_race_screen.py): every shape launched many
+    times, alone and beside a bandwidth-heavy copy on another stream; every result bit-identical to the first, the first
+    checked against fp64."""
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "tools", "bf16_gemm_race_screen.py"), "40"], capture_output=True,
+                       text=True, timeout=600)
+    assert p.returncode == 0 and "RACE SCREEN clean" in p.stdout, p.stdout[-2000:] + p.stderr[-2000:]
