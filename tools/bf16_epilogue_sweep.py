@@ -4,7 +4,9 @@ dGELU), to see what the epilogue costs beside the K loop.  DCLIP_BF16_PP=0 selec
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from dclip_amd import ops
+from dclip_amd import ops, _lib
+if len(sys.argv) > 1:                      # another build of the library (A/B on one box)
+    _lib.LIB_PATH = os.path.abspath(sys.argv[1])
 dev = torch.device("cuda:0")
 
 
