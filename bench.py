@@ -268,6 +268,10 @@ def main():
     else:
         teacher = PatchTextAggregation(embed_dim=cfg.projection_dim, num_heads=cfg.projection_dim // 64,
                                        clip_model=student).to(dev)
+    # the cross-modal block too from a seeded state (its constructor draws from the process's default RNG): the same frozen
+    # teacher in every run and on every rank
+    teacher.cross_modal_attention.load_state_dict(
+        {k: v.to(dev) for k, v in synth.synth_cross_modal_state_dict(teacher.embed_dim, seed=31).items()})
     hp = argparse.Namespace(learning_rate=1e-6, warmup_steps=0, total_steps=10 ** 6, train_batch_size=args.batch,
                             eval_batch_size=args.batch)
     module = CLIPImageDistillation(hp, student, None, teacher=teacher, freeze_mode="north_star",

@@ -75,6 +75,9 @@ SIGNATURES = {
     "dclip_gemm_bf16_splitk_plan": (I, [I, I, I]),
     "dclip_gemm_bf16_splitk_workspace": (Z, [I, I, I]),
     "dclip_gemm_bf16_splitk": (I, [P, P, P, I, I, I, I, I, I, I, P, Z, P]),
+    "dclip_gemm_bf16_wgrad_tokmajor_plan": (I, [I, I, I]),
+    "dclip_gemm_bf16_wgrad_tokmajor": (I, [P, P, P, I, I, I, I, I, I, I, P, Z, P]),
+    "dclip_colsum_bf16": (I, [P, P, I, I, I, I, P, Z, P]),
     "dclip_sumsq_blocks": (I, [Z]),
     "dclip_sumsq_f32": (I, [P, Z, P, P]),
     "dclip_clip_coef": (I, [P, I, F, P, P, P]),

@@ -634,6 +634,16 @@ __device__ __forceinline__ void pp_epilogue_b16(const GemmBf16Params& p, const f
 //        of the next tile), B0 one phase after (read first in phase 1 and retired by lgkmcnt(8) BEFORE that phase's
 //        first barrier).
 // Every wave executes the same number of s_barrier: wave row 1 one extra before the loop, wave row 0 one after it.
+// TOK (token-major operands, the weight gradients dW[out,in] = dY^T X of the bf16 training path WITHOUT the transposes):
+// A = dY [K = tokens][M = out] and W = X [K][N = in] are read as they lie.  A K-tile half is then a [64 k][256 B] LDS
+// image (the 64-column quadrant slices of the two wave rows / the 32-column slices of the four wave columns side by
+// side), filled by DMA pieces of 4 k-rows, and the MFMA operands — lane (l15, quad) needs 8 consecutive k of ONE column —
+// come out of it through the transposing LDS read (ds_read_b64_tr_b16: 4 k x 16 columns per 16 lanes, two per operand).
+// 16-byte granule g of k-row r is stored at g ^ (((r & 3) << 2) | (((r >> 3) & 1) << 1)): the 4 k-rows of a read and the
+// two lane groups of a half-wave (k-rows 8 apart) land on 32 different 8-byte bank pairs.  Same phases and barriers; the
+// DMA order is A1(kt+1) | - | A0(kt+2) | B0, B1(kt+2) (every half re-staged at least two phases after its last read, so
+// no lgkmcnt before a barrier is needed: phase 1 issues 24 reads, more than the 4-bit counter can express).
+template <bool TOK>
 __global__ void __launch_bounds__(512) gemm_bf16_pp_kernel(GemmBf16Params p) {
   constexpr int BM = 256, BN = 256, ROW = BKH;
   constexpr int BUF = (BM + BN) * ROW;   // bf16 elements per K-tile buffer: 256 A rows then 256 B rows of 128 bytes
@@ -662,46 +672,88 @@ __global__ void __launch_bounds__(512) gemm_bf16_pp_kernel(GemmBf16Params p) {
   const int kspan = (p.k_per_split ? min(p.K, kbeg + p.k_per_split) : p.K) - kbeg;
   const int nk = kspan / BKH;
 
-  const __bf16* a_org = p.A + (size_t)m0 * p.lda + kbeg;
-  const __bf16* w_org = p.W + (size_t)n0 * p.ldw + kbeg;
+  const __bf16* a_org = TOK ? p.A + (size_t)kbeg * p.lda + m0 : p.A + (size_t)m0 * p.lda + kbeg;
+  const __bf16* w_org = TOK ? p.W + (size_t)kbeg * p.ldw + n0 : p.W + (size_t)n0 * p.ldw + kbeg;
   const int a_rows = min(BM, p.M - m0), w_rows = min(BN, p.N - n0);
-  const size_t a_bytes = ((size_t)(a_rows - 1) * p.lda + (p.K - kbeg)) * 2,
-               w_bytes = ((size_t)(w_rows - 1) * p.ldw + (p.K - kbeg)) * 2;
+  const size_t a_bytes = TOK ? ((size_t)(p.K - kbeg - 1) * p.lda + a_rows) * 2 : ((size_t)(a_rows - 1) * p.lda + (p.K - kbeg)) * 2,
+               w_bytes = TOK ? ((size_t)(p.K - kbeg - 1) * p.ldw + w_rows) * 2 : ((size_t)(w_rows - 1) * p.ldw + (p.K - kbeg)) * 2;
   const __amdgpu_buffer_rsrc_t a_rsrc =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a_org), 0, (int)min(a_bytes, (size_t)0x7fffffff), 0x00020000);
   const __amdgpu_buffer_rsrc_t w_rsrc =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(w_org), 0, (int)min(w_bytes, (size_t)0x7fffffff), 0x00020000);
-  // DMA pieces (8 rows x 128 B, lane i -> row i >> 3, stored slot i & 7 = logical granule slot ^ ((row >> 1) & 7)).
+  // scalar byte advance per K-tile
+  const int a_kstep = TOK ? BKH * p.lda * 2 : BKH * 2, w_kstep = TOK ? BKH * p.ldw * 2 : BKH * 2;
+  // DMA pieces.  K-major: 8 rows x 128 B, lane i -> row i >> 3, stored slot i & 7 = logical granule slot ^ ((row >> 1) & 7);
   // A-half h: piece x of this wave covers rows 128 x + 64 h + 8 wave; B-half h: rows 64 (2 x + (wave >> 2)) + 32 h + 8 (wave & 3).
+  // Token-major: 4 k-rows x 256 B of a half image, piece x of this wave = k-rows 4 (wave + 8 x) ..; lane i -> k-row i >> 4,
+  // stored granule i & 15 = logical granule ^ swizzle(k-row); logical granule g of an A half-row holds columns 128 (g >> 3) +
+  // 64 h + 8 (g & 7) .., of a B half-row columns 64 (g >> 2) + 32 h + 8 (g & 3) ...
   int a_voff[2][2], w_voff[2][2];
 #pragma unroll
   for (int h = 0; h < 2; ++h)
 #pragma unroll
     for (int x = 0; x < 2; ++x) {
-      const int ra = 128 * x + 64 * h + 8 * wave + (lane >> 3), ga = (lane & 7) ^ ((ra >> 1) & 7);
-      a_voff[h][x] = ra < a_rows ? (ra * p.lda + ga * 8) * 2 : 0x7fffffff;   // out of range -> zeros in LDS
-      const int rb = 64 * (2 * x + (wave >> 2)) + 32 * h + 8 * (wave & 3) + (lane >> 3), gb = (lane & 7) ^ ((rb >> 1) & 7);
-      w_voff[h][x] = rb < w_rows ? (rb * p.ldw + gb * 8) * 2 : 0x7fffffff;
+      if (TOK) {
+        const int k = 4 * (wave + 8 * x) + (lane >> 4);
+        const int lg = (lane & 15) ^ (((k & 3) << 2) | (((k >> 3) & 1) << 1));
+        const int ma = 128 * (lg >> 3) + 64 * h + 8 * (lg & 7), nb = 64 * (lg >> 2) + 32 * h + 8 * (lg & 3);
+        a_voff[h][x] = ma < a_rows ? (k * p.lda + ma) * 2 : 0x7fffffff;     // columns past M / N -> zeros in LDS
+        w_voff[h][x] = nb < w_rows ? (k * p.ldw + nb) * 2 : 0x7fffffff;
+      } else {
+        const int ra = 128 * x + 64 * h + 8 * wave + (lane >> 3), ga = (lane & 7) ^ ((ra >> 1) & 7);
+        a_voff[h][x] = ra < a_rows ? (ra * p.lda + ga * 8) * 2 : 0x7fffffff;   // out of range -> zeros in LDS
+        const int rb = 64 * (2 * x + (wave >> 2)) + 32 * h + 8 * (wave & 3) + (lane >> 3), gb = (lane & 7) ^ ((rb >> 1) & 7);
+        w_voff[h][x] = rb < w_rows ? (rb * p.ldw + gb * 8) * 2 : 0x7fffffff;
+      }
     }
+  constexpr int HALF = 64 * 128;   // bf16 elements of a token-major half image (16 KiB): A0 | A1 | B0 | B1 per buffer
 #define PP_ISSUE_A(h, buf, kt)                                                                                          \
   do {                                                                                                                  \
-    dma16(a_rsrc, lds + (buf) * BUF + (64 * (h) + 8 * wave) * ROW, a_voff[h][0], (kt) * (BKH * 2));                     \
-    dma16(a_rsrc, lds + (buf) * BUF + (128 + 64 * (h) + 8 * wave) * ROW, a_voff[h][1], (kt) * (BKH * 2));               \
+    if (TOK) {                                                                                                          \
+      dma16(a_rsrc, lds + (buf) * BUF + (h) * HALF + wave * 512, a_voff[h][0], (kt) * a_kstep);                         \
+      dma16(a_rsrc, lds + (buf) * BUF + (h) * HALF + (wave + 8) * 512, a_voff[h][1], (kt) * a_kstep);                   \
+    } else {                                                                                                            \
+      dma16(a_rsrc, lds + (buf) * BUF + (64 * (h) + 8 * wave) * ROW, a_voff[h][0], (kt) * a_kstep);                     \
+      dma16(a_rsrc, lds + (buf) * BUF + (128 + 64 * (h) + 8 * wave) * ROW, a_voff[h][1], (kt) * a_kstep);               \
+    }                                                                                                                   \
   } while (0)
 #define PP_ISSUE_B(h, buf, kt)                                                                                          \
   do {                                                                                                                  \
-    dma16(w_rsrc, lds + (buf) * BUF + (BM + 64 * (wave >> 2) + 32 * (h) + 8 * (wave & 3)) * ROW, w_voff[h][0],          \
-          (kt) * (BKH * 2));                                                                                            \
-    dma16(w_rsrc, lds + (buf) * BUF + (BM + 128 + 64 * (wave >> 2) + 32 * (h) + 8 * (wave & 3)) * ROW, w_voff[h][1],    \
-          (kt) * (BKH * 2));                                                                                            \
+    if (TOK) {                                                                                                          \
+      dma16(w_rsrc, lds + (buf) * BUF + (2 + (h)) * HALF + wave * 512, w_voff[h][0], (kt) * w_kstep);                   \
+      dma16(w_rsrc, lds + (buf) * BUF + (2 + (h)) * HALF + (wave + 8) * 512, w_voff[h][1], (kt) * w_kstep);             \
+    } else {                                                                                                            \
+      dma16(w_rsrc, lds + (buf) * BUF + (BM + 64 * (wave >> 2) + 32 * (h) + 8 * (wave & 3)) * ROW, w_voff[h][0],        \
+            (kt) * w_kstep);                                                                                            \
+      dma16(w_rsrc, lds + (buf) * BUF + (BM + 128 + 64 * (wave >> 2) + 32 * (h) + 8 * (wave & 3)) * ROW, w_voff[h][1],  \
+            (kt) * w_kstep);                                                                                            \
+    }                                                                                                                   \
   } while (0)
 
-  // fragment addresses: row 16 blk + l15, k-step s: logical granule 4 s + quad, stored at granule ^ (l15 >> 1)
+  // fragment addresses.  K-major: row 16 blk + l15, k-step s: logical granule 4 s + quad, stored at granule ^ (l15 >> 1).
   const int sw = l15 >> 1;
   const __bf16* pa0 = lds + (128 * wr + l15) * ROW + (((0 + quad) ^ sw) << 3);
   const __bf16* pa1 = lds + (128 * wr + l15) * ROW + (((4 + quad) ^ sw) << 3);
   const __bf16* pb0 = lds + (BM + 64 * wc + l15) * ROW + (((0 + quad) ^ sw) << 3);
   const __bf16* pb1 = lds + (BM + 64 * wc + l15) * ROW + (((4 + quad) ^ sw) << 3);
+  // Token-major: a lane of a 16-lane group addresses k-row 8 quad + (l15 >> 2) (+ 32 s + 4 u) at columns 4 (l15 & 3) .. of the
+  // 16-column block and receives 4 consecutive k of column l15; block i of the A quadrant is granule 8 wr + 2 i + ((l15 & 3) >> 1),
+  // block j of the B quadrant granule 4 wc + 2 j + ((l15 & 3) >> 1), both XOR the lane's swizzle; byte 8 (l15 & 1) inside it.
+  const unsigned char* lds8 = lds_raw;
+  const int tq = l15 >> 2, swzl = (tq << 2) | ((quad & 1) << 1);
+  const int trow = (8 * quad + tq) * 256 + 8 * (l15 & 1);
+  int ta[4], tb[2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) ta[i] = trow + (((8 * wr + 2 * i + ((l15 & 3) >> 1)) ^ swzl) << 4);
+#pragma unroll
+  for (int j = 0; j < 2; ++j) tb[j] = trow + (((4 * wc + 2 * j + ((l15 & 3) >> 1)) ^ swzl) << 4);
+  auto tr8 = [&](int byte_off) {      // 8 consecutive k of this lane's column: two transposing reads, k-rows 4 apart
+    typedef short s16x4_t __attribute__((ext_vector_type(4)));
+    typedef short s16x8_t __attribute__((ext_vector_type(8)));
+    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(lds8 + byte_off));
+    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(lds8 + byte_off + 1024));
+    return __builtin_bit_cast(bf16x8, s16x8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]});
+  };
 
   f32x4 acc[8][4];
 #pragma unroll
@@ -712,13 +764,23 @@ __global__ void __launch_bounds__(512) gemm_bf16_pp_kernel(GemmBf16Params p) {
 
 #define PP_READ_A(qm, off)                                                                          \
   _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                   \
-    fa[i][0] = *reinterpret_cast<const bf16x8*>(pa0 + (off) + (64 * (qm) + 16 * i) * ROW);          \
-    fa[i][1] = *reinterpret_cast<const bf16x8*>(pa1 + (off) + (64 * (qm) + 16 * i) * ROW);          \
+    if (TOK) {                                                                                      \
+      fa[i][0] = tr8((off) * 2 + (qm) * (HALF * 2) + ta[i]);                                        \
+      fa[i][1] = tr8((off) * 2 + (qm) * (HALF * 2) + ta[i] + 32 * 256);                             \
+    } else {                                                                                        \
+      fa[i][0] = *reinterpret_cast<const bf16x8*>(pa0 + (off) + (64 * (qm) + 16 * i) * ROW);        \
+      fa[i][1] = *reinterpret_cast<const bf16x8*>(pa1 + (off) + (64 * (qm) + 16 * i) * ROW);        \
+    }                                                                                               \
   }
 #define PP_READ_B(fb, qn, off)                                                                      \
   _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                   \
-    fb[j][0] = *reinterpret_cast<const bf16x8*>(pb0 + (off) + (32 * (qn) + 16 * j) * ROW);          \
-    fb[j][1] = *reinterpret_cast<const bf16x8*>(pb1 + (off) + (32 * (qn) + 16 * j) * ROW);          \
+    if (TOK) {                                                                                      \
+      fb[j][0] = tr8((off) * 2 + (2 + (qn)) * (HALF * 2) + tb[j]);                                  \
+      fb[j][1] = tr8((off) * 2 + (2 + (qn)) * (HALF * 2) + tb[j] + 32 * 256);                       \
+    } else {                                                                                        \
+      fb[j][0] = *reinterpret_cast<const bf16x8*>(pb0 + (off) + (32 * (qn) + 16 * j) * ROW);        \
+      fb[j][1] = *reinterpret_cast<const bf16x8*>(pb1 + (off) + (32 * (qn) + 16 * j) * ROW);        \
+    }                                                                                               \
   }
 #define PP_MFMA(qm, qn, fb)                                                                                         \
   do {                                                                                                              \
@@ -757,7 +819,7 @@ __global__ void __launch_bounds__(512) gemm_bf16_pp_kernel(GemmBf16Params p) {
     PP_READ_A(0, off);
     __builtin_amdgcn_sched_barrier(0);
     if (n1) PP_ISSUE_A(1, cur ^ 1, kt + 1);
-    asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");   // the B reads are done: their rows may be re-staged next phase
+    if (!TOK) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");   // the B reads are done: their rows may be re-staged next phase
     PP_BARRIER();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
@@ -766,7 +828,7 @@ __global__ void __launch_bounds__(512) gemm_bf16_pp_kernel(GemmBf16Params p) {
     // ---- phase 2
     PP_READ_B(fb1, 1, off);
     __builtin_amdgcn_sched_barrier(0);
-    if (n2) PP_ISSUE_B(0, cur, kt + 2);
+    if (!TOK && n2) PP_ISSUE_B(0, cur, kt + 2);
     PP_BARRIER();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
@@ -783,6 +845,7 @@ __global__ void __launch_bounds__(512) gemm_bf16_pp_kernel(GemmBf16Params p) {
     PP_BARRIER();
     // ---- phase 4
     if (n2) {
+      if (TOK) PP_ISSUE_B(0, cur, kt + 2);               // (token-major: B0 here instead of phase 2, see the kernel's header)
       PP_ISSUE_B(1, cur, kt + 2);
       asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // tile kt+1 has landed (this wave's pieces)
     } else {
@@ -826,10 +889,11 @@ __global__ void __launch_bounds__(512) gemm_bf16_pp_kernel(GemmBf16Params p) {
 }
 #undef PP_BARRIER
 
-int launch_pp(GemmBf16Params p, hipStream_t st, int splits = 1) {
+int launch_pp(GemmBf16Params p, hipStream_t st, int splits = 1, bool tok_major = false) {
   p.tiles_m = cdiv(p.M, 256);
   p.tiles_n = cdiv(p.N, 256);
-  hipLaunchKernelGGL(gemm_bf16_pp_kernel, dim3(p.tiles_m * p.tiles_n, splits), dim3(512), 0, st, p);
+  if (tok_major) hipLaunchKernelGGL(gemm_bf16_pp_kernel<true>, dim3(p.tiles_m * p.tiles_n, splits), dim3(512), 0, st, p);
+  else hipLaunchKernelGGL(gemm_bf16_pp_kernel<false>, dim3(p.tiles_m * p.tiles_n, splits), dim3(512), 0, st, p);
   return DCLIP_OK;
 }
 
@@ -975,6 +1039,54 @@ DCLIP_API int dclip_gemm_bf16_ex(const void* A, const void* W, void* C, const fl
   if (small) hipLaunchKernelGGL((gemm_bf16_kernel<64, 64>), dim3(p.tiles_m * p.tiles_n), dim3(256), lds, st, p);
   else hipLaunchKernelGGL((gemm_bf16_kernel<128, 128>), dim3(p.tiles_m * p.tiles_n), dim3(256), lds, st, p);
   DCLIP_CHECK_LAUNCH("gemm_bf16");
+  return DCLIP_OK;
+}
+
+// dW[M = out][N = in] fp32 = dY^T X from the operands as the backward has them: dY [K = tokens][lddy >= M], X [K][ldx >= N],
+// bf16, token-major — no transposes.  Split-K over the tokens on the ping-pong kernel (token-major form), fixed-order reduce.
+// dclip_gemm_bf16_wgrad_tokmajor_plan = the split count to pass, 0 when this form does not apply (K % 64, M / N % 8, too few
+// work items for the chip, or DCLIP_BF16_PP=0): the caller then transposes and uses dclip_gemm_bf16_splitk.
+DCLIP_API int dclip_gemm_bf16_wgrad_tokmajor_plan(int M, int N, int K) {
+  if (K % BKH != 0 || M % 8 != 0 || N % 8 != 0 || !pingpong_enabled()) return 0;
+  const long t256 = (long)cdiv(M, 256) * cdiv(N, 256);
+  int s = t256 >= 256 ? 1 : (int)(256 / t256);
+  const int kmax = K / 512 > 0 ? K / 512 : 1;                 // at least 8 K-tiles per work item
+  s = s > kmax ? kmax : s;
+  s = s > 64 ? 64 : s;
+  return t256 * s >= 128 ? s : 0;
+}
+
+DCLIP_API int dclip_gemm_bf16_wgrad_tokmajor(const void* dY, const void* X, float* C, int M, int N, int K, int lddy, int ldx,
+                                             int ldc, int splits, void* workspace, size_t workspace_bytes, void* stream) {
+  DCLIP_REQUIRE(dY && X && C, "gemm_bf16_wgrad_tokmajor: null operand");
+  DCLIP_REQUIRE(M > 0 && N > 0 && K > 0 && K % BKH == 0 && M % 8 == 0 && N % 8 == 0 && splits >= 1 && splits <= 64,
+                "gemm_bf16_wgrad_tokmajor: M=%d N=%d (multiples of 8) K=%d (multiple of 64) splits=%d", M, N, K, splits);
+  DCLIP_REQUIRE(lddy % 8 == 0 && ldx % 8 == 0 && lddy >= M && ldx >= N && ldc % 4 == 0 && ldc >= N,
+                "gemm_bf16_wgrad_tokmajor: leading dimensions");
+  DCLIP_REQUIRE(((uintptr_t)dY | (uintptr_t)X | (uintptr_t)C) % 16 == 0, "gemm_bf16_wgrad_tokmajor: operands must be 16-byte aligned");
+  DCLIP_REQUIRE(pingpong_enabled(), "gemm_bf16_wgrad_tokmajor: needs the ping-pong kernel (DCLIP_BF16_PP=0 is set)");
+  const int kps = cdiv(cdiv(K, splits), BKH) * BKH;
+  const int s_eff = cdiv(K, kps);
+  hipStream_t st = (hipStream_t)stream;
+  if (s_eff == 1) {
+    GemmBf16Params pb{(const __bf16*)dY, (const __bf16*)X, C, nullptr, nullptr, M, N, K, lddy, ldx, ldc, 0, 0, 0, 0, nullptr, 0, nullptr};
+    launch_pp(pb, st, 1, true);
+    DCLIP_CHECK_LAUNCH("gemm_bf16_wgrad_tokmajor");
+    return DCLIP_OK;
+  }
+  const size_t need = (size_t)s_eff * M * N * sizeof(float);
+  if (!workspace || workspace_bytes < need) {
+    dclip_set_error("gemm_bf16_wgrad_tokmajor: needs %zu workspace bytes, got %zu", need, workspace_bytes);
+    return DCLIP_EWORKSPACE;
+  }
+  DCLIP_REQUIRE((uintptr_t)workspace % 16 == 0, "gemm_bf16_wgrad_tokmajor: workspace must be 16-byte aligned");
+  GemmBf16Params pb{(const __bf16*)dY, (const __bf16*)X, C, nullptr, nullptr, M, N, K, lddy, ldx, ldc, 0, 0, 0, 0, nullptr, kps,
+                    (float*)workspace};
+  launch_pp(pb, st, s_eff, true);
+  DCLIP_CHECK_LAUNCH("gemm_bf16_wgrad_tokmajor");
+  hipLaunchKernelGGL(splitk_reduce_bf16_kernel, dim3(grid_for((size_t)M * N / 4)), dim3(256), 0, st, (const float*)workspace, C, M,
+                     N, ldc, s_eff);
+  DCLIP_CHECK_LAUNCH("gemm_bf16_wgrad_tokmajor.reduce");
   return DCLIP_OK;
 }
 

@@ -173,6 +173,32 @@ __global__ void __launch_bounds__(1024) reduce_partials_kernel(const float* __re
 }
 
 // column sums: block = 64 float4-columns x 4 row lanes; grid.y splits the rows
+// bf16 form (the fc1 bias gradient of the bf16 training path: dh exists only as bf16 [tokens][I])
+__global__ void __launch_bounds__(256) colsum_bf16_kernel(const unsigned short* __restrict__ X, float* __restrict__ partial, int M,
+                                                          int N, int ldx) {
+  typedef unsigned short u16x4_t __attribute__((ext_vector_type(4)));
+  __shared__ f32x4 red[4][64];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c4 = blockIdx.x * 64 + cl;
+  const int n4 = N >> 2;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  if (c4 < n4) {
+    const int rows_per = (M + gridDim.y - 1) / gridDim.y;
+    const int r0 = blockIdx.y * rows_per, r1 = min(M, r0 + rows_per);
+    for (int r = r0 + rl; r < r1; r += 4) {
+      const u16x4_t b = *reinterpret_cast<const u16x4_t*>(X + (size_t)r * ldx + c4 * 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) s[e] += __builtin_bit_cast(float, (unsigned int)b[e] << 16);
+    }
+  }
+  red[rl][cl] = s;
+  __syncthreads();
+  if (rl == 0 && c4 < n4) {
+    f32x4 t = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
+    *reinterpret_cast<f32x4*>(partial + (size_t)blockIdx.y * N + c4 * 4) = t;
+  }
+}
+
 __global__ void __launch_bounds__(256) colsum_kernel(const float* __restrict__ X, float* __restrict__ partial, int M,
                                                      int N, int ldx) {
   __shared__ f32x4 red[4][64];
@@ -284,5 +310,26 @@ DCLIP_API int dclip_colsum_f32(const float* X, float* out, int M, int N, int ldx
   hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(N, RP_COLS)), dim3(1024), 0, st, (const float*)workspace, out,
                      (float*)nullptr, splits, N, 0, accumulate);
   DCLIP_CHECK_LAUNCH("colsum.reduce");
+  return DCLIP_OK;
+}
+
+// out[n] = sum_m X[m][n] over a bf16 matrix [M][ldx] (same workspace size as dclip_colsum_f32_workspace(M, N))
+DCLIP_API int dclip_colsum_bf16(const void* X, float* out, int M, int N, int ldx, int accumulate, void* workspace,
+                                size_t workspace_bytes, void* stream) {
+  DCLIP_REQUIRE(X && out, "colsum_bf16: null pointer");
+  DCLIP_REQUIRE(M > 0 && N > 0 && N % 4 == 0 && ldx % 4 == 0 && ldx >= N, "colsum_bf16: bad shape M=%d N=%d ldx=%d", M, N, ldx);
+  DCLIP_REQUIRE((uintptr_t)X % 8 == 0, "colsum_bf16: alignment");
+  const int splits = colsum_splits(M);
+  if (!workspace || workspace_bytes < (size_t)splits * N * sizeof(float)) {
+    dclip_set_error("colsum_bf16: workspace too small");
+    return DCLIP_EWORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(colsum_bf16_kernel, dim3(cdiv(N / 4, 64), splits), dim3(256), 0, st, (const unsigned short*)X,
+                     (float*)workspace, M, N, ldx);
+  DCLIP_CHECK_LAUNCH("colsum_bf16");
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(N, RP_COLS)), dim3(1024), 0, st, (const float*)workspace, out,
+                     (float*)nullptr, splits, N, 0, accumulate);
+  DCLIP_CHECK_LAUNCH("colsum_bf16.reduce");
   return DCLIP_OK;
 }

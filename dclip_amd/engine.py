@@ -14,9 +14,11 @@ from __future__ import annotations
 from dataclasses import dataclass
 from typing import Dict, List, Optional
 
+import os
+
 import torch
 
-from . import ops
+from . import _lib, ops
 
 
 @dataclass
@@ -371,10 +373,72 @@ def _wgrad_bf16(dyT, xT, M: int, need_w: bool):
     return ops.gemm_bf16_wgrad(dyT, xT, M) if need_w else None
 
 
+def _tokmajor_wgrads(M: int, D: int, I: int) -> bool:
+    """Can the four weight gradients of a layer take the token-major form (no transposes)?  One answer per layer so that
+    the backward below has two straight schedules.  DCLIP_BF16_WGRAD_TN=0 forces the transposing schedule (A/B aid)."""
+    if os.environ.get("DCLIP_BF16_WGRAD_TN", "1") == "0":
+        return False
+    lib = _lib.load()
+    return all(lib.dclip_gemm_bf16_wgrad_tokmajor_plan(m, n, M) > 0 for m, n in ((D, I), (I, D), (D, D), (3 * D, D)))
+
+
+def layer_bwd_bf16_tokmajor(dx2, p: LayerParams, c: dict, pre: str, saved, B: int, S: int, H: int, causal: bool,
+                            need: Dict[str, bool]):
+    """layer_bwd_bf16 with the weight gradients read from the operands as they lie — dW = dY^T X on the token-major form of
+    the ping-pong GEMM (ops.gemm_bf16_wgrad_tokmajor): the fp32 gradients are only CAST to bf16 (the copy the data-gradient
+    GEMM needs anyway), the saved bf16 activations are used as they are, no transposed copies are written."""
+    x, m1, r1, ln1, qkv, attn, attn16, lse, x1, m2, r2, ln2, h16, g16 = saved
+    D = x.shape[1]
+    gr: Dict[str, torch.Tensor] = {}
+    # ---- fc2
+    dx2_16 = ops.cast_bf16(dx2)
+    if need.get("fc2_w"):
+        gr["fc2_w"] = ops.gemm_bf16_wgrad_tokmajor(dx2_16, g16)
+    if need.get("fc2_b"):
+        gr["fc2_b"] = ops.colsum(dx2)
+    dh16 = ops.gemm_bf16(dx2_16, _w16t(c, pre + "fc2", p.fc2_w), k=D, dgelu_of=h16, out_bf16=True)       # [M, I]
+    del dx2_16
+    # ---- fc1
+    if need.get("fc1_w"):
+        gr["fc1_w"] = ops.gemm_bf16_wgrad_tokmajor(dh16, ln2)
+    if need.get("fc1_b"):
+        gr["fc1_b"] = ops.colsum_bf16(dh16)
+    dln2 = ops.gemm_bf16(dh16, _w16t(c, pre + "fc1", p.fc1_w), k=dh16.shape[1])                          # [M, D] fp32
+    del dh16
+    want_ln2 = bool(need.get("ln2_w") or need.get("ln2_b"))
+    dx1, dg, db = ops.layernorm_bwd(dln2, x1, p.ln2_w, m2, r2, dresidual=dx2, need_param_grads=want_ln2)
+    if want_ln2:
+        gr["ln2_w"], gr["ln2_b"] = dg, db
+    # ---- out_proj
+    dx1_16 = ops.cast_bf16(dx1)
+    if need.get("out_w"):
+        gr["out_w"] = ops.gemm_bf16_wgrad_tokmajor(dx1_16, attn16)
+    if need.get("out_b"):
+        gr["out_b"] = ops.colsum(dx1)
+    dattn = ops.gemm_bf16(dx1_16, _w16t(c, pre + "out", p.out_w), k=D)                                   # [M, D] fp32
+    del dx1_16
+    dqkv = ops.attention_bwd(qkv, attn, dattn, lse, B, S, H, causal)                                     # fp32 [M, 3D]
+    # ---- qkv projection
+    dqkv16 = ops.cast_bf16(dqkv)
+    if need.get("qkv_w"):
+        gr["qkv_w"] = ops.gemm_bf16_wgrad_tokmajor(dqkv16, ln1)
+    if need.get("qkv_b"):
+        gr["qkv_b"] = ops.colsum(dqkv)
+    dln1 = ops.gemm_bf16(dqkv16, _w16t(c, pre + "qkv", p.qkv_w), k=3 * D)
+    del dqkv, dqkv16
+    want_ln1 = bool(need.get("ln1_w") or need.get("ln1_b"))
+    dx, dg, db = ops.layernorm_bwd(dln1, x, p.ln1_w, m1, r1, dresidual=dx1, need_param_grads=want_ln1)
+    if want_ln1:
+        gr["ln1_w"], gr["ln1_b"] = dg, db
+    return dx, gr
+
+
 def layer_bwd_bf16(dx2, p: LayerParams, c: dict, pre: str, saved, B: int, S: int, H: int, causal: bool, need: Dict[str, bool]):
     x, m1, r1, ln1, qkv, attn, attn16, lse, x1, m2, r2, ln2, h16, g16 = saved
     M = x.shape[0]
     D = x.shape[1]
+    if _tokmajor_wgrads(M, D, g16.shape[1]):
+        return layer_bwd_bf16_tokmajor(dx2, p, c, pre, saved, B, S, H, causal, need)
     gr: Dict[str, torch.Tensor] = {}
     # ---- fc2
     dx2T, dx2_16 = ops.transpose_bf16(dx2, want_copy=True)

@@ -737,6 +737,39 @@ def gemm_bf16_wgrad(a: torch.Tensor, w: torch.Tensor, k: int, splits: Optional[i
     return out
 
 
+def gemm_bf16_wgrad_tokmajor(dy: torch.Tensor, x: torch.Tensor) -> Optional[torch.Tensor]:
+    """dW [out, in] fp32 = dy^T x from the token-major bf16 operands dy [tokens, out], x [tokens, in] as the backward has
+    them (no transposes).  Returns None when the library's token-major form does not apply to the shape (the caller then
+    transposes and uses gemm_bf16_wgrad)."""
+    lib = _lib.load()
+    _bf16(dy, "dy"), _bf16(x, "x")
+    K, M = dy.shape
+    K2, N = x.shape
+    if K != K2:
+        raise ValueError("gemm_bf16_wgrad_tokmajor: token counts differ")
+    splits = lib.dclip_gemm_bf16_wgrad_tokmajor_plan(M, N, K)
+    if splits == 0:
+        return None
+    out = torch.empty((M, N), dtype=torch.float32, device=dy.device)
+    nbytes = lib.dclip_gemm_bf16_splitk_workspace(M, N, splits)
+    ws = _ws.get(nbytes, dy.device)
+    _lib.check(lib.dclip_gemm_bf16_wgrad_tokmajor(dy.data_ptr(), x.data_ptr(), out.data_ptr(), M, N, K, M, N, N, splits,
+                                                  _ptr(ws), nbytes, _stream()), "gemm_bf16_wgrad_tokmajor")
+    return out
+
+
+def colsum_bf16(x: torch.Tensor) -> torch.Tensor:
+    """Column sums (over the rows = tokens) of a bf16 matrix, fp32 result: a bias gradient from a bf16 dY."""
+    lib = _lib.load()
+    _bf16(x, "x")
+    M, N = x.shape
+    out = torch.empty((N,), dtype=torch.float32, device=x.device)
+    nbytes = lib.dclip_colsum_f32_workspace(M, N)
+    ws = _ws.get(nbytes, x.device)
+    _lib.check(lib.dclip_colsum_bf16(x.data_ptr(), out.data_ptr(), M, N, N, 0, _ptr(ws), nbytes, _stream()), "colsum_bf16")
+    return out
+
+
 # ------------------------------------------------------------------------------------------- crop front end
 
 def crop_resize(images_u8: torch.Tensor, dims: torch.Tensor, boxes: torch.Tensor, size: int,

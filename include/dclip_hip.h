@@ -308,6 +308,18 @@ int dclip_gemm_bf16_splitk_plan(int M, int N, int K);
 size_t dclip_gemm_bf16_splitk_workspace(int M, int N, int splits);
 int dclip_gemm_bf16_splitk(const void* A, const void* W, float* C, int M, int N, int K, int lda, int ldw, int ldc,
                            int splits, void* workspace, size_t workspace_bytes, void* stream);
+/* The same weight gradient WITHOUT the transposes: dY [K = tokens][lddy >= M] and X [K][ldx >= N] bf16 as the backward has
+ * them (token-major); C [M][ldc] fp32 = dY^T X.  Split-K over the tokens on the token-major form of the ping-pong kernel
+ * (operands out of LDS through the transposing read), fixed-order reduce through `workspace`
+ * (dclip_gemm_bf16_splitk_workspace(M, N, splits) bytes).  dclip_gemm_bf16_wgrad_tokmajor_plan(M, N, K) = the split count to
+ * pass, or 0 when this form does not apply (K % 64, M or N % 8, too few work items): transpose and use
+ * dclip_gemm_bf16_splitk then.  dclip_colsum_bf16: the bias gradient sum over tokens of a bf16 [M][ldx] matrix
+ * (workspace as dclip_colsum_f32_workspace). */
+int dclip_gemm_bf16_wgrad_tokmajor_plan(int M, int N, int K);
+int dclip_gemm_bf16_wgrad_tokmajor(const void* dY, const void* X, float* C, int M, int N, int K, int lddy, int ldx, int ldc,
+                                   int splits, void* workspace, size_t workspace_bytes, void* stream);
+int dclip_colsum_bf16(const void* X, float* out, int M, int N, int ldx, int accumulate, void* workspace,
+                      size_t workspace_bytes, void* stream);
 /* Softmax attention of the frozen towers on bf16 q/k/v (the fused projection [B*S, 3*H*64] as written by
  * dclip_gemm_bf16 with out_bf16): fp32 scores / softmax, bf16 P and context [B*S, H*64].  Forward only. */
 int dclip_attention_fwd_bf16(const void* qkv, void* out, int B, int S, int H, int causal, void* stream);

@@ -166,3 +166,59 @@ def test_bf16_student_c3_step_loss_vs_oracle():
     opt.zero_grad(set_to_none=True)
     loss2 = mod.training_step(batch)
     assert float(loss2.detach()) < got            # the update was seen by the bf16 weight copies (version-keyed cache)
+
+
+@pytest.mark.parametrize("M,N,K", [(768, 768, 12800), (768, 3072, 12800), (3072, 768, 12800), (2304, 768, 12800), (768, 768, 3200),
+                                   (264, 520, 1280), (1024, 4096, 3200), (776, 1032, 25600)])
+def test_gemm_bf16_wgrad_tokmajor(M, N, K):
+    """dW = dY^T X straight from the token-major bf16 operands (no transposes): against fp64 of the rounded inputs, equal
+    to itself on repetition, and within fp32-accumulation noise of the transposing path."""
+    from dclip_amd import ops
+    dev = torch.device("cuda:0")
+    dy, x = rnd((K, M), 1).to(torch.bfloat16), rnd((K, N), 2).to(torch.bfloat16)
+    got = ops.gemm_bf16_wgrad_tokmajor(dy.to(dev), x.to(dev))
+    if got is None:                       # the library declined the shape (too few work items for 256 CUs)
+        from dclip_amd import _lib
+        assert _lib.load().dclip_gemm_bf16_wgrad_tokmajor_plan(M, N, K) == 0 and (M, N, K) in ((768, 768, 3200), (264, 520, 1280))
+        return
+    want = dy.double().t() @ x.double()
+    assert float((got.double().cpu() - want).abs().max() / want.abs().max()) < 2e-6 * max(1.0, K ** 0.5)
+    assert torch.equal(got, ops.gemm_bf16_wgrad_tokmajor(dy.to(dev), x.to(dev)))
+    other = ops.gemm_bf16_wgrad(ops.transpose_bf16(dy.to(dev)), ops.transpose_bf16(x.to(dev)), K)
+    assert float((got - other).abs().max() / want.abs().max()) < 2e-6 * max(1.0, K ** 0.5)
+
+
+def test_colsum_bf16():
+    from dclip_amd import ops
+    dev = torch.device("cuda:0")
+    x = rnd((12800, 3072), 5).to(torch.bfloat16)
+    got = ops.colsum_bf16(x.to(dev))
+    want = x.double().sum(0)
+    assert float((got.double().cpu() - want).abs().max() / want.abs().max()) < 1e-5
+
+
+def test_bf16_layer_backward_schedules_agree(monkeypatch):
+    """The token-major weight-gradient schedule (default) and the transposing one (DCLIP_BF16_WGRAD_TN=0) give the same
+    gradients up to fp32 accumulation order."""
+    from dclip_amd.clip_model import from_hf_state_dict
+    dev = torch.device("cuda:0")
+    cfg = dcfg.vit_b32()
+    sd = synth.synth_clip_state_dict(cfg, seed=3)
+    B = 256                                                          # 12,800 tokens: the token-major form applies to all four shapes
+    pix = synth.synth_pixel_values(B, cfg.vision, seed=0).to(dev)
+    ids = synth.synth_input_ids(B, cfg.text, seed=3, ragged=True).to(dev)
+    t_img = synth.synth_embeddings(B, cfg.projection_dim, seed=1).to(dev)
+    grads = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("DCLIP_BF16_WGRAD_TN", flag)
+        m = from_hf_state_dict(cfg, sd, device=dev)
+        for p_ in m.text_model.parameters():
+            p_.requires_grad = False
+        m.text_projection.weight.requires_grad = False
+        m.logit_scale.requires_grad = False
+        _loss, _img, g = _step(m, pix, ids, t_img, "bf16")
+        grads.append(g)
+    for n in grads[0]:
+        a, b = grads[0][n], grads[1][n]
+        cos = float((a @ b) / (a.norm() * b.norm() + 1e-30))
+        assert cos > 0.999999, (n, cos)
