@@ -480,7 +480,10 @@ def main():
             traffic_source = "profiles/gemm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, " \
                              "committed; NOT re-measured in this run)"
         if args.workload == "c2":
-            wl = (f"BASELINE config c2: {cfg.name} distill step, bs={B}/GPU, 224x224 + {T}-token synthetic pairs, "
+            tag = "c2" if (cfg.name == "ViT-B/32" and B == 256) else \
+                  ("c4, one GPU's share of the global batch (extra, not the benched config)" if cfg.name == "ViT-B/16" else
+                   "c2's step at another model / batch (extra, not the benched config)")
+            wl = (f"BASELINE config {tag}: {cfg.name} distill step, bs={B}/GPU, 224x224 + {T}-token synthetic pairs, "
                   f"contrastive+cosine loss, fp32, vision trainable / text frozen (north_star regime), ")
         else:
             wl = (f"BASELINE config {args.workload} (extra, not the benched config): {cfg.name} student "
