@@ -404,10 +404,22 @@ __global__ void __launch_bounds__(256) attn_fwd_stream_kernel(AttnArgs a, float*
   const bool wave_live = q0 < S;                        // a wave past the end only helps staging
   int nkt = (S + TS - 1) / TS;
   if (CAUSAL) nkt = min(nkt, (int)(blockIdx.y * 128 + 127) / TS + 1);
+  // The next K / V tile is requested into registers BEFORE the current tile's products (32 VGPRs; the kernel stays at two
+  // waves per SIMD) and written to LDS behind them: a tile's memory latency used to sit between two barriers with the
+  // matrix pipe idle, once per tile.
+  f32x4 nk4[4], nv4[4];
+  tile_fetch(nk4, kbase, 0, S, (size_t)a.ldkv);
+  tile_fetch(nv4, vbase, 0, S, (size_t)a.ldkv);
   for (int kt = 0; kt < nkt; ++kt) {
-    if (kt > 0) __syncthreads();
-    stage_tiles2(Ks, kbase, (size_t)a.ldkv, Vs, vbase, (size_t)a.ldkv, kt * TS, S);
+    if (kt > 0) __syncthreads();                         // everybody is done reading the previous tile
+    tile_commit(Ks, nk4, kt * TS, S);
+    tile_commit(Vs, nv4, kt * TS, S);
     __syncthreads();
+    if (kt + 1 < nkt) {
+      tile_fetch(nk4, kbase, (kt + 1) * TS, S, (size_t)a.ldkv);
+      tile_fetch(nv4, vbase, (kt + 1) * TS, S, (size_t)a.ldkv);
+    }
+    __builtin_amdgcn_sched_barrier(0);
     if (!wave_live || (CAUSAL && kt * TS > q0 + 31)) continue;
     // second 32-key half of the tile: skipped when it holds no key this wave needs (wave-uniform)
     const bool sub1 = kt * TS + 32 < S && !(CAUSAL && kt * TS + 32 > q0 + 31);
