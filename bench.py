@@ -27,12 +27,19 @@ sys.path.insert(0, REPO)
 # pool's boxes; set here as well so a bare launch behaves the same)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
-if os.environ.get("DCLIP_BENCH_TRACE_AFTER") and "RANK" in os.environ:   # debugging aid (ranks only): dump the Python stacks after N s, exit
-    import faulthandler
-    faulthandler.dump_traceback_later(int(os.environ["DCLIP_BENCH_TRACE_AFTER"]), exit=True)
+import faulthandler  # noqa: E402
 
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
+
+# Watchdog, default ON: a run that has not finished after this many seconds (counted from here, i.e. after `import torch`,
+# which alone can take two minutes on a fresh box) dumps every thread's Python stack to stderr and exits non-zero — an
+# N-rank run cannot die silently or sit in a collective until the driver's limit.  Ranks: 240 s (a healthy 8-rank run
+# needs well under a minute after import); the single process, which also times the CPU baseline: 900 s.
+WATCHDOG_S = int(os.environ.get("DCLIP_BENCH_WATCHDOG_S", os.environ.get("DCLIP_BENCH_TRACE_AFTER", "240" if "RANK" in os.environ else "900")))
+if WATCHDOG_S > 0:
+    faulthandler.dump_traceback_later(WATCHDOG_S, exit=True)
+PG_TIMEOUT_S = float(os.environ.get("DCLIP_BENCH_PG_TIMEOUT_S", "180"))
 
 from dclip_amd import config as dcfg, synth  # noqa: E402
 
@@ -176,9 +183,20 @@ def self_launch(n: int) -> int:
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
     env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
-    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
-    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
-    for ln in proc.stdout.splitlines():
+    # own session: if the ranks' watchdogs somehow do not fire, the whole launch (launcher + ranks = one process group, the
+    # one started here) is ended by its group id after the watchdog time plus the import / rendezvous allowance
+    limit = (WATCHDOG_S + 150) if WATCHDOG_S > 0 else None
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, start_new_session=True)
+    try:
+        out, _ = proc.communicate(timeout=limit)
+    except subprocess.TimeoutExpired:
+        import signal
+        os.killpg(proc.pid, signal.SIGKILL)
+        out, _ = proc.communicate()
+        print(f"bench.py: the {n}-rank launch did not finish within {limit} s and was killed", file=sys.stderr)
+        return 124
+    lines = [ln for ln in out.splitlines() if ln.startswith("{") and '"metric"' in ln]
+    for ln in out.splitlines():
         if ln not in lines:
             print(ln, file=sys.stderr)
     if proc.returncode == 0 and lines:
@@ -247,7 +265,15 @@ def main():
     torch.cuda.set_device(local_rank % ndev)
     dev = torch.device("cuda", local_rank % ndev)
     from dclip_amd import dist as ddist
-    group = ddist.init_from_env(backend) if world > 1 else None
+    group = ddist.init_from_env(backend, timeout_s=PG_TIMEOUT_S) if world > 1 else None
+    # per-rank progress lines on stderr (host time since start; the host runs ahead of the GPU except where a collective or
+    # a synchronize holds it): default on for gloo rehearsals, DCLIP_BENCH_STEP_LOG=1 elsewhere
+    step_log = os.environ.get("DCLIP_BENCH_STEP_LOG", "1" if (world > 1 and backend == "gloo") else "0") == "1"
+    t_start = time.perf_counter()
+
+    def note(msg):
+        if step_log:
+            print(f"[rank {rank} +{time.perf_counter() - t_start:7.2f}s] {msg}", file=sys.stderr, flush=True)
 
     from dclip_amd.clip_model import from_hf_state_dict
     from dclip_amd.CLIP_image_distillation import CLIPImageDistillation
@@ -278,7 +304,7 @@ def main():
                                    process_group=group, student_precision=args.student_precision).to(dev)
     trainable = [p for p in module.parameters() if p.requires_grad]
     opt = None if args.no_optimizer else optim.FusedAdamW(trainable, lr=hp.learning_rate, max_grad_norm=0.5)
-    sync = ddist.GradSync(trainable, group) if world > 1 else None
+    sync = ddist.GradSync(trainable, group, timing=True) if world > 1 else None
     if sync is not None:            # gradient all-reduce overlapped with the backward pass
         from dclip_amd import functional
         functional.set_grad_ready_hook(sync.on_grads_ready)
@@ -393,8 +419,10 @@ def main():
             el = float(t)
         return el, out
 
-    for _ in range(args.warmup):
+    note("model + batch resident; warm-up starts")
+    for i_ in range(args.warmup):
         step()
+        note(f"warm-up step {i_} launched")
     if sync is not None:
         sync.reset_stats()
     # HIP events around every GEMM launch cost ~1.8 % of the step (400 event records; measured 65.54 vs 64.38 ms on one
@@ -408,14 +436,28 @@ def main():
         timer.enabled = on
         sampled["n"] += int(on)
         sampled["i"] += 1
-        return step(eager_now=on)
+        out_ = step(eager_now=on)
+        note(f"timed step {sampled['i'] - 1} launched")
+        return out_
 
     elapsed, last = timed(args.steps, timed_step)      # ---- THE timed region: exactly K steps
     timer.enabled = False
     n_sampled = max(1, sampled["n"])
     last_loss = float(last.detach())
     del last
+    note(f"timed region done: {elapsed * 1e3 / args.steps:.2f} ms/step")
     comm = sync.stats() if sync is not None else None
+    if sync is not None:
+        # calibration leg (every rank): each gradient bucket all-reduced alone -> ms per bucket and the bus rate
+        # 2(N-1)/N x bytes / time the collective reaches with nothing beside it
+        per_bucket = sync.bucket_allreduce_ms()
+        nbytes = sync.bucket_bytes()
+        tot_ms, tot_b = sum(per_bucket), sum(nbytes)
+        comm["allreduce_ms_per_bucket_alone"] = [round(x, 3) for x in per_bucket]
+        comm["bucket_bytes"] = nbytes
+        comm["allreduce_ms_per_step_alone"] = round(tot_ms, 3)
+        comm["allreduce_busbw_GBps_alone"] = round(2.0 * (world - 1) / world * tot_b / (tot_ms * 1e-3) / 1e9, 2) if tot_ms else None
+        note("bucket calibration done")
 
     # ---- extra legs, outside the contract's timed region ("optimizer excluded and reported separately")
     extra = {}
@@ -451,6 +493,25 @@ def main():
                 del gs
             except Exception as exc:            # a graph variant is informative only; never fail the bench line on it
                 extra["graph_error"] = f"{type(exc).__name__}: {exc}"[:200]
+
+    if world > 1 and not args.no_extra_legs:
+        # The same step WITHOUT the data-parallel parts, launched the same way (eagerly) on every rank at once: local
+        # negatives only, no gradient all-reduce.  N-rank `value` / (N x this) is the scaling efficiency of like with like
+        # (the N = 1 default line replays a HIP graph, ~3 % faster than eager launches).  After the timed region: the
+        # replicas may drift apart here, nothing reads them afterwards.
+        from dclip_amd import functional as _fn
+        _fn.set_grad_ready_hook(None)
+        _fn.set_grad_alloc(None)
+        module.process_group = None
+        sync_saved, sync = sync, None
+        n_x = max(3, min(args.steps, 10))
+        for _ in range(2):
+            step()
+        el, _ = timed(n_x, step)
+        extra["n1_eager_ms_per_step"] = round(el * 1e3 / n_x, 3)
+        extra["n1_eager_images_per_s"] = round(B * n_x / el, 2)
+        sync = sync_saved
+        note("single-GPU eager leg done")
 
     if rank == 0:
         ms_per_step = elapsed * 1e3 / args.steps
@@ -563,6 +624,7 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    faulthandler.cancel_dump_traceback_later()
 
 
 if __name__ == "__main__":

@@ -23,8 +23,11 @@ import torch
 import torch.distributed as dist
 
 
-def init_from_env(backend: Optional[str] = None):
-    """Rendezvous from RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT (torch.distributed.run sets them)."""
+def init_from_env(backend: Optional[str] = None, timeout_s: float = 180.0):
+    """Rendezvous from RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT (torch.distributed.run sets them).
+    `timeout_s` bounds the rendezvous AND every collective (RCCL's watchdog aborts the process when one has been pending
+    that long; gloo raises from `wait()`): a rank that dies or falls behind cannot park the others for the backend's
+    default 10 / 30 minutes."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world == 1:
         return None
@@ -37,7 +40,8 @@ def init_from_env(backend: Optional[str] = None):
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":
             torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % max(1, torch.cuda.device_count()))
-        dist.init_process_group(backend=backend)
+        import datetime
+        dist.init_process_group(backend=backend, timeout=datetime.timedelta(seconds=float(timeout_s)))
     return dist.group.WORLD
 
 
@@ -71,15 +75,22 @@ class GradSync:
         reducer owns these gradients (autograd is handed None for them — nothing is accumulated or cloned);
       * `finish()` (after `loss.backward()`) takes whatever no hook delivered from `.grad` (parameters outside the hooked
         tower), zero-fills slices of parameters that received no gradient, launches the remaining buckets, waits, and
-        points every delivered parameter's `.grad` at its slice of the reduced bucket.
+        points EVERY parameter's `.grad` at its slice of the reduced bucket (a parameter that produced no gradient on
+        this rank still receives the other ranks' sum, as under DDP: replicas cannot diverge).
     Without the hooks installed, `reduce()` = finish() does everything after the backward (still bucketed and
-    asynchronous among buckets).  One backward per `finish()`: with gradient accumulation call it after the LAST
-    micro-batch only and without the overlap hooks (the hook sees a micro-batch's gradients, not the accumulated ones).
-    The buckets are reused every step: the optimizer must have consumed `.grad` before the next backward starts (same
-    stream: it has)."""
+    asynchronous among buckets).
 
-    def __init__(self, params: Iterable[torch.nn.Parameter], group, bucket_mb: float = 25.0):
+    Gradient accumulation (the reference trains with accumulate_grad_batches=4,
+    training/CLIP_image_distill_training.py:42): run the first micro-batches WITHOUT the hooks (`hooks()` not entered;
+    autograd accumulates into `.grad` as usual) and the LAST one inside `with sync.hooks():` — a hook delivery adds the
+    `.grad` accumulated so far to the micro-batch's gradient in the bucket slice and clears it, so the all-reduce of the
+    accumulated gradient still overlaps the last micro-batch's backward.  One `finish()` per optimizer step.
+    The buckets are reused every step: the optimizer must have consumed `.grad` before the next hooked backward starts
+    (same stream: it has), and `.grad` must be cleared (`zero_grad(set_to_none=True)`) before the next un-hooked one."""
+
+    def __init__(self, params: Iterable[torch.nn.Parameter], group, bucket_mb: float = 25.0, timing: bool = False):
         self.group = group
+        self.timing = timing        # record HIP events around finish()'s waits (bench.py: "exposed" all-reduce time)
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
         self._ids = {id(p) for p in self.params}
         self.bucket_elems = max(1, int(bucket_mb * (1 << 20) / 4))
@@ -114,22 +125,61 @@ class GradSync:
         self._n_bytes = 0
         self._n_inplace = 0
         self._n_copied = 0
-        self._wait_events = []      # (before, after) event pairs around finish()'s waits, on the compute stream
+        self._wait_events = []      # (before, after) event pairs around finish()'s waits (only with timing=True)
+        self._wait_ms = 0.0         # pairs already read out (the list is drained every 64 steps: bounded)
+
+    def _drain_wait_events(self):
+        if self._wait_events:
+            torch.cuda.synchronize()
+            self._wait_ms += sum(a.elapsed_time(b) for a, b in self._wait_events)
+            self._wait_events = []
 
     def stats(self) -> dict:
         """Per-step averages since reset_stats(): buckets all-reduced, bytes all-reduced, gradients written in place vs
-        copied into their slice, and the EXPOSED all-reduce time (how long the compute stream sat in finish() waiting
-        for RCCL after the backward had ended)."""
+        copied into their slice, and (timing=True) the EXPOSED all-reduce time — how long the compute stream sat in
+        finish() waiting for RCCL after the backward had ended."""
         n = max(1, self._n_finish)
         exposed = None
-        if self._wait_events:
-            torch.cuda.synchronize()
-            exposed = sum(a.elapsed_time(b) for a, b in self._wait_events) / n
+        if self.timing and (self._wait_events or self._wait_ms):
+            self._drain_wait_events()
+            exposed = self._wait_ms / n
         return {"grad_buckets_per_step": self._n_buckets / n, "grad_allreduce_bytes_per_step": self._n_bytes / n,
                 "grad_tensors_written_in_place_per_step": self._n_inplace / n,
                 "grad_tensors_copied_per_step": self._n_copied / n,
                 "grad_allreduce_exposed_ms_per_step": None if exposed is None else round(exposed, 4),
                 "bucket_mb": round(self.bucket_elems * 4 / (1 << 20), 2)}
+
+    def bucket_allreduce_ms(self, repeats: int = 3) -> List[float]:
+        """Calibration leg (outside any timed region): every bucket all-reduced ALONE, synchronously, `repeats` times;
+        mean milliseconds per bucket, in launch order.  With the bucket sizes this gives the bus rate the collective
+        reaches when nothing overlaps it.  Collective call: every rank must make it.  The buckets' contents are
+        multiplied by world**repeats — call it only between steps (the next backward overwrites them)."""
+        out = []
+        for b in range(len(self._bucket_params)):
+            flat = self._flat[b]
+            if flat is None:
+                out.append(0.0)
+                continue
+            flat.zero_()
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)          # warm: connections, protocol choice
+            if flat.is_cuda:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(repeats):
+                    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+                e1.record()
+                e1.synchronize()
+                out.append(e0.elapsed_time(e1) / repeats)
+            else:
+                import time
+                t0 = time.perf_counter()
+                for _ in range(repeats):
+                    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+                out.append((time.perf_counter() - t0) * 1e3 / repeats)
+        return out
+
+    def bucket_bytes(self) -> List[int]:
+        return [4 * n for n in self._bucket_size]
 
     # ---- buffers
     def _bucket(self, b: int, device) -> torch.Tensor:
@@ -154,8 +204,25 @@ class GradSync:
             return None
         return self._view(p).view(tuple(shape))
 
+    def hooks(self):
+        """Context manager: install `on_grads_ready` / `grad_buffer` as the towers' data-parallel hooks for ONE backward
+        (the last micro-batch of an accumulation group, or the only one), remove them on exit."""
+        import contextlib
+        from . import functional
+
+        @contextlib.contextmanager
+        def _cm():
+            functional.set_grad_ready_hook(self.on_grads_ready)
+            functional.set_grad_alloc(self.grad_buffer)
+            try:
+                yield self
+            finally:
+                functional.set_grad_ready_hook(None)
+                functional.set_grad_alloc(None)
+        return _cm()
+
     # ---- called during backward
-    def _deliver(self, p, g):
+    def _deliver(self, p, g, from_hook: bool = False):
         if id(p) in self._seen:
             # a second delivery within one backward (a tower applied twice) would overwrite the first in the bucket
             raise RuntimeError("GradSync: a parameter's gradient was delivered twice in one backward; use "
@@ -169,6 +236,11 @@ class GradSync:
         else:
             v.copy_(g.reshape(-1))
             self._n_copied += 1
+        if from_hook and p.grad is not None:
+            # earlier micro-batches of this accumulation group (run without the hooks) left their sum in .grad
+            if p.grad.data_ptr() != v.data_ptr():
+                v.add_(p.grad.reshape(-1))
+            p.grad = None
         b = self._slot[id(p)][0]
         self._arrived[b] += 1
         if self._arrived[b] == len(self._bucket_params[b]):
@@ -180,7 +252,7 @@ class GradSync:
         for p, g in pairs:
             if g is None or id(p) not in self._ids:
                 continue
-            self._deliver(p, g)
+            self._deliver(p, g, from_hook=True)
         return True
 
     def _launch(self, b: int):
@@ -205,13 +277,10 @@ class GradSync:
     def finish(self):
         if self.group is None:
             return
-        delivered = set(self._seen)
         for p in reversed(self.params):                 # whatever no hook delivered (other towers, heads)
             if id(p) not in self._seen:
-                if p.grad is not None:
-                    delivered.add(id(p))
                 self._deliver(p, p.grad)                # None: the slice is zero-filled (the other ranks may have one)
-        timed = bool(self._work) and self._flat[self._work[0][0]].is_cuda
+        timed = self.timing and bool(self._work) and self._flat[self._work[0][0]].is_cuda
         if timed:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -220,12 +289,26 @@ class GradSync:
         if timed:
             e1.record()
             self._wait_events.append((e0, e1))
+            if len(self._wait_events) >= 64:
+                self._drain_wait_events()
         for p in self.params:                           # zero-copy: .grad is a view of the reduced bucket
-            if id(p) in delivered:
-                p.grad = self._view(p).view_as(p)
+            p.grad = self._view(p).view_as(p)
         self._n_finish += 1
         self._work, self._seen = [], set()
         self._arrived = [0] * len(self._bucket_params)
         self._launched = [False] * len(self._bucket_params)
 
     reduce = finish
+
+
+def shard_batches(batches: Iterable, rank: int, world: int):
+    """Rank `rank`'s share of a stream of per-GPU batches: batch i goes to rank i % world; a trailing group that does
+    not cover every rank is dropped, so all ranks run the SAME number of steps (a rank with one step more would wait in
+    its collectives for ever).  The single-process equivalent of one N-rank step is the concatenation of the N batches
+    of a group."""
+    group = []
+    for b in batches:
+        group.append(b)
+        if len(group) == world:
+            yield group[rank]
+            group = []

@@ -105,12 +105,23 @@ def _with_last_flag(iterable):
 
 
 class Trainer:
-    """`Trainer(max_epochs, accelerator="gpu", devices=1, precision=32, gradient_clip_val=0.5,
-    accumulate_grad_batches=4, callbacks=[ModelCheckpoint(...)]).fit(model)` — the subset the launcher uses."""
+    """`Trainer(max_epochs, accelerator="gpu", devices=N, precision=32, gradient_clip_val=0.5,
+    accumulate_grad_batches=4, callbacks=[ModelCheckpoint(...)]).fit(model)` — the subset the launcher uses
+    (training/CLIP_image_distill_training.py:36-45).
+
+    `devices` > 1 (or an explicit `process_group`) trains data-parallel, one process per GPU over RCCL: the processes are
+    started by `python -m torch.distributed.run --nproc-per-node N …` (the launcher script starts them itself when
+    called bare, dclip_amd/CLIP_image_distill_training.py) and `fit` joins the rendezvous found in the environment.
+    Every loader batch is a PER-GPU batch: batch i of the stream goes to rank i % N (`dist.shard_batches`), the loss uses
+    global negatives (all-gathered embeddings), gradients are SUM-reduced in persistent buckets with the all-reduce
+    launched from inside the LAST micro-batch's backward (`dist.GradSync`, accumulation keeps the overlap), rank 0 writes
+    the checkpoints, and the logged / file-name `train_loss` is the global loss (`dist.global_loss_value`).  N ranks on
+    batches b_0 … b_{N-1} perform exactly the update of one process on their concatenation."""
 
     def __init__(self, max_epochs: int = 1, gradient_clip_val: Optional[float] = 0.5, accumulate_grad_batches: int = 4,
                  checkpoint_dir: Optional[str] = None, save_top_k: int = 10, max_steps: Optional[int] = None,
-                 use_hip_graph: bool = False, lr_interval: str = "epoch", **_ignored):
+                 use_hip_graph: bool = False, lr_interval: str = "epoch", devices: int = 1, process_group=None,
+                 dist_backend: Optional[str] = None, bucket_mb: float = 25.0, **_ignored):
         """`use_hip_graph`: replay forward+backward from a captured HIP graph (dclip_amd/graph.py) — tensor batches of
         one fixed shape, single process; the update sequence and its results are those of the eager loop.
         `lr_interval`: "epoch" (default) advances the LR schedule once per epoch — what Lightning does with the
@@ -128,15 +139,46 @@ class Trainer:
         self.save_top_k = save_top_k
         self.max_steps = max_steps
         self.saved = []          # (train_loss, path)
+        self.devices = int(devices) if isinstance(devices, int) else len(devices)
+        self.process_group = process_group
+        self.dist_backend = dist_backend
+        self.bucket_mb = bucket_mb
+        self.grad_sync = None
+
+    def _join_group(self):
+        """The data-parallel group of this run: the one passed in, else (devices > 1) the rendezvous in the environment."""
+        if self.process_group is not None or self.devices <= 1:
+            return self.process_group
+        import torch.distributed as tdist
+        from . import dist as ddist
+        if not tdist.is_initialized() and int(os.environ.get("WORLD_SIZE", "1")) != self.devices:
+            raise RuntimeError(
+                f"Trainer(devices={self.devices}) runs one process per GPU: start it with `python -m torch.distributed.run "
+                f"--nnodes=1 --nproc-per-node {self.devices} --master-addr 127.0.0.1 <script> ...` "
+                f"(found WORLD_SIZE={os.environ.get('WORLD_SIZE', 'unset')})")
+        return ddist.init_from_env(self.dist_backend or os.environ.get("DCLIP_DIST_BACKEND"))
 
     def fit(self, model: LightningLikeModule, train_dataloaders: Optional[Iterable] = None,
             val_dataloaders: Optional[Iterable] = None):
+        group = self._join_group()
+        world, rank = 1, 0
+        if group is not None:
+            import torch.distributed as tdist
+            from . import dist as ddist
+            world, rank = tdist.get_world_size(group), tdist.get_rank(group)
+            if self.use_hip_graph:
+                raise RuntimeError("use_hip_graph captures a single-process step; data-parallel runs launch eagerly")
+            model.process_group = group                   # global negatives + the per-rank loss share (dist.py)
         opts, scheds = model.configure_optimizers()
         opt, sched = opts[0], (scheds[0] if scheds else None)
         # the HIP optimizer clips the global norm itself (device-side coefficient, no host sync, one pass over the grads)
         fused_clip = bool(self.clip) and hasattr(opt, "max_grad_norm")
         if fused_clip:
             opt.max_grad_norm = self.clip
+        sync = None
+        if group is not None:
+            sync = ddist.GradSync([p for g in opt.param_groups for p in g["params"]], group, bucket_mb=self.bucket_mb)
+            self.grad_sync = sync
         train = train_dataloaders if train_dataloaders is not None else model.train_dataloader()
         val = val_dataloaders if val_dataloaders is not None else (
             model.val_dataloader() if hasattr(model, "val_dataloader") else None)
@@ -150,7 +192,8 @@ class Trainer:
             elif acc is not None:
                 torch._foreach_zero_(acc)          # nothing of the previous epoch leaks into this epoch's first update
             last = None
-            for i, batch, is_last in _with_last_flag(train):
+            stream = train if group is None else ddist.shard_batches(train, rank, world)
+            for i, batch, is_last in _with_last_flag(stream):
                 # Lightning steps on every `accum`-th batch AND on the last batch of the epoch (a trailing partial
                 # group is not dropped); the divisor stays `accum` there as well
                 boundary = (i + 1) % self.accum == 0 or is_last
@@ -168,6 +211,15 @@ class Trainer:
                         if boundary:
                             torch._foreach_copy_([p.grad for p in gparams], acc)
                             torch._foreach_zero_(acc)
+                elif sync is not None:
+                    loss = model.training_step(batch)          # this rank's SHARE of the global loss
+                    if boundary:
+                        with sync.hooks():                     # all-reduce launched from inside this backward
+                            (loss / self.accum).backward()
+                        sync.finish()
+                    else:
+                        (loss / self.accum).backward()         # plain accumulation into .grad
+                    last = (loss.detach(), dict(getattr(model, "last_losses", {})))
                 else:
                     loss = model.training_step(batch)
                     (loss / self.accum).backward()
@@ -189,18 +241,30 @@ class Trainer:
             if val is not None:
                 model.eval()
                 with torch.no_grad():
-                    for batch in val:
+                    for batch in (val if group is None else ddist.shard_batches(val, rank, world)):
                         model.validation_step(batch)
+            if group is not None and last is not None:
+                # the value Lightning would log on one process: sum of the ranks' shares (one small all-reduce per epoch)
+                share, parts = last
+                if parts:
+                    last = ddist.global_loss_value(parts["loss_image"], parts["loss_text"], parts["loss_contrastive"], group)
+                else:
+                    last = share.clone()
+                    tdist.all_reduce(last, group=group)
+                model.log("train_loss", last)
             if self.checkpoint_dir and last is not None:
                 tl = float(last)
                 path = os.path.join(self.checkpoint_dir, checkpoint_filename(epoch, tl))
-                save_checkpoint(path, model, opt, sched, epoch, step)
-                self.saved.append((tl, path))
-                self.saved.sort()
-                for _, stale in self.saved[self.save_top_k:]:
-                    if os.path.exists(stale):
-                        os.remove(stale)
-                self.saved = self.saved[:self.save_top_k]
+                if rank == 0:
+                    save_checkpoint(path, model, opt, sched, epoch, step)
+                    self.saved.append((tl, path))
+                    self.saved.sort()
+                    for _, stale in self.saved[self.save_top_k:]:
+                        if os.path.exists(stale):
+                            os.remove(stale)
+                    self.saved = self.saved[:self.save_top_k]
+                if group is not None:
+                    tdist.barrier(group=group)      # nobody races ahead of (or reads) a half-written checkpoint
             if self.max_steps is not None and step >= self.max_steps:
                 break
         return model

@@ -11,6 +11,11 @@ What is kept (training/train_contrastive_teacher.py):
   * `torch.save(teacher.state_dict(), f"{stem}_epoch{N}_val{loss:.4f}.pth")` every epoch, best → `output_path`,
     `output_path + ".interrupt.pth"` / `".error.pth"` on Ctrl-C / exception (:394-420).
 
+Data parallel ("the teacher trainer shards identically"; the reference is single-GPU): under
+`python -m torch.distributed.run --nproc-per-node N -m dclip_amd.train_contrastive_teacher …` (or with `process_group=`)
+batch i goes to rank i % N, the InfoNCE uses global negatives, the 12 gradient tensors (8.4 MB) are SUM-reduced in one
+bucket, rank 0 writes the checkpoints; N ranks perform the update of one process on the concatenated batches.
+
 What differs: models are never fetched by name — `args.clip_path` names a LOCAL directory with HF CLIP weights (or
 `teacher=` is passed in); batches may be the reference's `(images, captions, paths, boxes)` tuples (needs a
 tokenizer) or tensor dicts `{regions, input_ids[, region_counts]}`; the DBM KNN cache (:19-95) feeds only the
@@ -105,9 +110,22 @@ def build_teacher(args, device) -> PatchTextAggregation:
 
 
 def main(args, teacher: Optional[PatchTextAggregation] = None, train_batches: Optional[Iterable] = None,
-         val_batches: Optional[Iterable] = None):
+         val_batches: Optional[Iterable] = None, process_group=None):
     seed_everything(42)
-    device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
+    from . import dist as ddist
+    group = process_group
+    if group is None and int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        group = ddist.init_from_env(os.environ.get("DCLIP_DIST_BACKEND"))
+    world, rank = 1, 0
+    if group is not None:
+        import torch.distributed as tdist
+        world, rank = tdist.get_world_size(group), tdist.get_rank(group)
+    if teacher is not None:
+        device = teacher.device
+    elif torch.cuda.is_available():
+        device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")) % max(1, torch.cuda.device_count()))
+    else:
+        device = torch.device("cpu")
     if teacher is None:
         teacher = build_teacher(args, device)
 
@@ -117,8 +135,9 @@ def main(args, teacher: Optional[PatchTextAggregation] = None, train_batches: Op
         if any(key in name for key in ["cross_attn", "attention", "proj", "fusion", "final"]):
             param.requires_grad = True
     trainable = [p for p in teacher.parameters() if p.requires_grad]
-    print(f"Training {sum(p.numel() for p in trainable):,} parameters out of "
-          f"{sum(p.numel() for p in teacher.parameters()):,}")
+    if rank == 0:
+        print(f"Training {sum(p.numel() for p in trainable):,} parameters out of "
+              f"{sum(p.numel() for p in teacher.parameters()):,}")
 
     if train_batches is None:
         train_batches = JsonPairDataset(args.train_file, args.batch_size, shuffle=True)
@@ -130,16 +149,29 @@ def main(args, teacher: Optional[PatchTextAggregation] = None, train_batches: Op
         optimizer = FusedAdam(trainable, lr=args.learning_rate)      # optim.Adam(trainable_params, lr) (:245-248)
     else:                                                            # CPU: argument / checkpoint plumbing only
         optimizer = torch.optim.Adam(trainable, lr=args.learning_rate)
+    sync = ddist.GradSync(trainable, group) if group is not None else None      # 8.4 MB: one bucket
+
+    def sharded(batches):
+        return batches if group is None else ddist.shard_batches(batches, rank, world)
+
+    def global_value(share_sum):
+        """Sum over ranks of the per-rank loss shares accumulated on the device (one small all-reduce per epoch)."""
+        if group is None or not isinstance(share_sum, torch.Tensor):
+            return float(share_sum)
+        v = share_sum.detach().clone()
+        tdist.all_reduce(v, group=group)
+        return float(v)
 
     def validate():
         teacher.eval()
         total, n = 0.0, 0
         with torch.no_grad():
-            for batch in (val_batches or []):
+            for batch in sharded(val_batches or []):
                 img, txt = _embeddings(teacher, batch)
-                total += float(compute_contrastive_loss(img, txt))
+                v = compute_contrastive_loss(img, txt, group=group)
+                total = total + (v.detach() if group is not None else float(v))
                 n += 1
-        return {"combined": total / max(1, n)}
+        return {"combined": global_value(total) / max(1, n)}
 
     out_dir = os.path.dirname(args.output_path)
     if out_dir:
@@ -150,27 +182,35 @@ def main(args, teacher: Optional[PatchTextAggregation] = None, train_batches: Op
         for epoch in range(args.epochs):
             teacher.train()
             epoch_loss, n = 0.0, 0
-            for batch_idx, batch in enumerate(train_batches):
+            for batch_idx, batch in enumerate(sharded(train_batches)):
                 optimizer.zero_grad()
                 img_emb, txt_emb = _embeddings(teacher, batch)
-                loss = compute_contrastive_loss(img_emb, txt_emb)
+                loss = compute_contrastive_loss(img_emb, txt_emb, group=group)     # N ranks: this rank's share
                 loss.backward()
+                if sync is not None:
+                    sync.finish()
                 optimizer.step()
-                epoch_loss += float(loss.detach())
+                epoch_loss = epoch_loss + (loss.detach() if group is not None else float(loss.detach()))
                 n += 1
-            avg_loss = epoch_loss / max(1, n)
+            avg_loss = global_value(epoch_loss) / max(1, n)
             val_losses = validate()
             history.append((avg_loss, val_losses["combined"]))
-            print(f"Epoch {epoch + 1}/{args.epochs}  train {avg_loss:.4f}  val {val_losses['combined']:.4f}")
-            epoch_save_path = f"{args.output_path.rsplit('.', 1)[0]}_epoch{epoch + 1}_val{val_losses['combined']:.4f}.pth"
-            torch.save(teacher.state_dict(), epoch_save_path)
+            if rank == 0:
+                print(f"Epoch {epoch + 1}/{args.epochs}  train {avg_loss:.4f}  val {val_losses['combined']:.4f}")
+                epoch_save_path = f"{args.output_path.rsplit('.', 1)[0]}_epoch{epoch + 1}_val{val_losses['combined']:.4f}.pth"
+                torch.save(teacher.state_dict(), epoch_save_path)
             if val_losses["combined"] < best_val_loss:
                 best_val_loss = val_losses["combined"]
-                torch.save(teacher.state_dict(), args.output_path)
+                if rank == 0:
+                    torch.save(teacher.state_dict(), args.output_path)
+            if group is not None:
+                tdist.barrier(group=group)
     except KeyboardInterrupt:
-        torch.save(teacher.state_dict(), args.output_path + ".interrupt.pth")
+        if rank == 0:
+            torch.save(teacher.state_dict(), args.output_path + ".interrupt.pth")
     except Exception:
-        torch.save(teacher.state_dict(), args.output_path + ".error.pth")
+        if rank == 0:
+            torch.save(teacher.state_dict(), args.output_path + ".error.pth")
         raise
     return {"best_val_loss": best_val_loss, "history": history}
 
@@ -187,8 +227,14 @@ def build_parser() -> argparse.ArgumentParser:
     parser.add_argument("--output_path", type=str, default="./teacher_contrastive/contrastive_teacher_ViT-16.pth",
                         help="Path to save the trained teacher model")
     parser.add_argument("--clip_path", type=str, default=None, help="LOCAL directory with HF CLIP weights + tokenizer")
+    parser.add_argument("--devices", type=int, default=1, help="GPUs of this node (one process per GPU, RCCL)")
     return parser
 
 
 if __name__ == "__main__":
-    main(build_parser().parse_args())
+    import sys
+    _args = build_parser().parse_args()
+    if _args.devices > 1 and "WORLD_SIZE" not in os.environ:
+        from .CLIP_image_distill_training import launch_ranks
+        raise SystemExit(launch_ranks(_args.devices, "dclip_amd.train_contrastive_teacher", sys.argv[1:]))
+    main(_args)
