@@ -188,14 +188,29 @@ class HipCLIPModel(nn.Module):
         return functional.VisionTowerFn.apply(pixel_values.float(), v, v.num_hidden_layers, *p.tensors())
 
     def _bf16_cache(self) -> dict:
-        """bf16 copies of the GEMM weights, rebuilt whenever any parameter was modified in place (optimizer step,
-        load_state_dict): keyed on the parameters' version counters."""
-        ver = tuple(p._version for p in self.parameters())
+        """bf16 copies of the GEMM weights: persistent buffers, each refreshed in place when ITS parameter's version
+        counter has moved (optimizer step, load_state_dict) — engine._w16 / _w16t.  A frozen tower's copies are made once."""
         c = getattr(self, "_bf16_w", None)
-        if c is None or c.get("__ver__") != ver:
-            c = {"__ver__": ver}
+        if c is None:
+            c = {}
             object.__setattr__(self, "_bf16_w", c)
         return c
+
+    def invalidate_bf16_of_trainable(self) -> int:
+        """Mark the bf16 copies of every TRAINABLE parameter stale (frozen towers keep theirs).  graph.GraphedStep calls
+        this between its eager warm-up and the capture: the weight casts / transposes are then part of the captured step
+        and every replay converts the CURRENT fp32 masters — without it a replay would multiply by the copies made
+        at warm-up while the optimizer keeps updating the masters.  Returns the number of entries marked."""
+        c = getattr(self, "_bf16_w", None)
+        if not c:
+            return 0
+        ptrs = {p.data_ptr() for p in self.parameters() if p.requires_grad}
+        n = 0
+        for e in c.values():
+            if e[2] in ptrs:
+                e[1] = -1
+                n += 1
+        return n
 
     def get_text_features(self, input_ids: torch.Tensor = None, attention_mask=None, precision: str = "fp32",
                           **kwargs) -> torch.Tensor:

@@ -295,11 +295,20 @@ def vision_bwd(p: VisionParams, saved, d_out: torch.Tensor, cfg, need: List[bool
 # producing kernel), accumulation, residual stream, LayerNorm statistics, softmax and biases stay fp32.
 
 def _w16(cache: dict, key: str, w: torch.Tensor) -> torch.Tensor:
-    t = cache.get(key)
-    if t is None:
-        t = ops.cast_bf16(w.detach().reshape(w.shape[0], -1).contiguous())
-        cache[key] = t
-    return t
+    """bf16 copy of a GEMM weight, PERSISTENT: entry = [tensor, version of `w` it was made from, data pointer of `w`].
+    When the optimizer (or load_state_dict) has written `w` since — the version counter is shared with the Parameter a
+    detached view came from — the copy is refreshed IN PLACE, so the buffer a captured HIP graph reads stays the one
+    that is kept current (and a capture started on a stale entry records the cast: every replay then re-reads the fp32
+    masters, HipCLIPModel.invalidate_bf16_of_trainable)."""
+    e = cache.get(key)
+    src = w.detach().reshape(w.shape[0], -1)
+    if e is None:
+        e = [ops.cast_bf16(src.contiguous()), w._version, w.data_ptr()]
+        cache[key] = e
+    elif e[1] != w._version or e[2] != w.data_ptr():
+        ops.cast_bf16(src.contiguous(), out=e[0])
+        e[1], e[2] = w._version, w.data_ptr()
+    return e[0]
 
 
 def _layer_fwd_bf16(x, p: LayerParams, c: dict, pre: str, B: int, S: int, H: int, causal: bool, eps: float):
@@ -349,11 +358,15 @@ def vision_fwd_bf16(p: VisionParams, pixel_values: torch.Tensor, cfg, cache: dic
 
 def _w16t(cache: dict, key: str, w: torch.Tensor) -> torch.Tensor:
     """bf16 W^T [in, ld >= out] of an nn.Linear weight [out, in]: the `W` operand of the dgrad GEMM dX = dY (W^T)^T."""
-    t = cache.get(key + ".T")
-    if t is None:
-        t = ops.transpose_bf16(w.detach().reshape(w.shape[0], -1).contiguous())
-        cache[key + ".T"] = t
-    return t
+    e = cache.get(key + ".T")
+    src = w.detach().reshape(w.shape[0], -1)
+    if e is None:
+        e = [ops.transpose_bf16(src.contiguous()), w._version, w.data_ptr()]
+        cache[key + ".T"] = e
+    elif e[1] != w._version or e[2] != w.data_ptr():
+        ops.transpose_bf16(src.contiguous(), out=e[0])
+        e[1], e[2] = w._version, w.data_ptr()
+    return e[0]
 
 
 def layer_fwd_bf16_train(x, p: LayerParams, c: dict, pre: str, B: int, S: int, H: int, causal: bool, eps: float):
@@ -368,119 +381,119 @@ def layer_fwd_bf16_train(x, p: LayerParams, c: dict, pre: str, B: int, S: int, H
     return x2, (x, m1, r1, ln1, qkv, attn, attn16, lse, x1, m2, r2, ln2, h16, g16)
 
 
-def _wgrad_bf16(dyT, xT, M: int, need_w: bool):
-    """dW [out, in] fp32 = dY^T X from the token-contiguous bf16 operands dY^T [out, ld], X^T [in, ld]."""
-    return ops.gemm_bf16_wgrad(dyT, xT, M) if need_w else None
+_TOKMAJOR_PLAN: Dict[tuple, bool] = {}
 
 
 def _tokmajor_wgrads(M: int, D: int, I: int) -> bool:
     """Can the four weight gradients of a layer take the token-major form (no transposes)?  One answer per layer so that
-    the backward below has two straight schedules.  DCLIP_BF16_WGRAD_TN=0 forces the transposing schedule (A/B aid)."""
-    if os.environ.get("DCLIP_BF16_WGRAD_TN", "1") == "0":
-        return False
-    lib = _lib.load()
-    return all(lib.dclip_gemm_bf16_wgrad_tokmajor_plan(m, n, M) > 0 for m, n in ((D, I), (I, D), (D, D), (3 * D, D)))
+    the backward below has two straight schedules; decided once per (M, D, I) (four plan calls + an environment lookup
+    per layer per backward otherwise).  DCLIP_BF16_WGRAD_TN=0, read at the first use, forces the transposing schedule."""
+    key = (M, D, I)
+    hit = _TOKMAJOR_PLAN.get(key)
+    if hit is None:
+        if os.environ.get("DCLIP_BF16_WGRAD_TN", "1") == "0":
+            hit = False
+        else:
+            lib = _lib.load()
+            hit = all(lib.dclip_gemm_bf16_wgrad_tokmajor_plan(m, n, M) > 0 for m, n in ((D, I), (I, D), (D, D), (3 * D, D)))
+        _TOKMAJOR_PLAN[key] = hit
+    return hit
 
 
 def layer_bwd_bf16_tokmajor(dx2, p: LayerParams, c: dict, pre: str, saved, B: int, S: int, H: int, causal: bool,
-                            need: Dict[str, bool]):
+                            need: Dict[str, bool], alloc=None):
     """layer_bwd_bf16 with the weight gradients read from the operands as they lie — dW = dY^T X on the token-major form of
     the ping-pong GEMM (ops.gemm_bf16_wgrad_tokmajor): the fp32 gradients are only CAST to bf16 (the copy the data-gradient
     GEMM needs anyway), the saved bf16 activations are used as they are, no transposed copies are written."""
     x, m1, r1, ln1, qkv, attn, attn16, lse, x1, m2, r2, ln2, h16, g16 = saved
     D = x.shape[1]
+    I = g16.shape[1]
+    dev = x.device
     gr: Dict[str, torch.Tensor] = {}
     # ---- fc2
     dx2_16 = ops.cast_bf16(dx2)
     if need.get("fc2_w"):
-        gr["fc2_w"] = ops.gemm_bf16_wgrad_tokmajor(dx2_16, g16)
+        gr["fc2_w"] = ops.gemm_bf16_wgrad_tokmajor(dx2_16, g16, out=_galloc(alloc, "fc2_w", (D, I), dev))
     if need.get("fc2_b"):
-        gr["fc2_b"] = ops.colsum(dx2)
+        gr["fc2_b"] = ops.colsum(dx2, out=_galloc(alloc, "fc2_b", (D,), dev))
     dh16 = ops.gemm_bf16(dx2_16, _w16t(c, pre + "fc2", p.fc2_w), k=D, dgelu_of=h16, out_bf16=True)       # [M, I]
     del dx2_16
     # ---- fc1
     if need.get("fc1_w"):
-        gr["fc1_w"] = ops.gemm_bf16_wgrad_tokmajor(dh16, ln2)
+        gr["fc1_w"] = ops.gemm_bf16_wgrad_tokmajor(dh16, ln2, out=_galloc(alloc, "fc1_w", (I, D), dev))
     if need.get("fc1_b"):
-        gr["fc1_b"] = ops.colsum_bf16(dh16)
+        gr["fc1_b"] = ops.colsum_bf16(dh16, out=_galloc(alloc, "fc1_b", (I,), dev))
     dln2 = ops.gemm_bf16(dh16, _w16t(c, pre + "fc1", p.fc1_w), k=dh16.shape[1])                          # [M, D] fp32
     del dh16
-    want_ln2 = bool(need.get("ln2_w") or need.get("ln2_b"))
-    dx1, dg, db = ops.layernorm_bwd(dln2, x1, p.ln2_w, m2, r2, dresidual=dx2, need_param_grads=want_ln2)
-    if want_ln2:
-        gr["ln2_w"], gr["ln2_b"] = dg, db
+    dx1 = _ln_bwd(dln2, x1, p.ln2_w, m2, r2, dx2, bool(need.get("ln2_w") or need.get("ln2_b")), gr, "ln2_w", "ln2_b", alloc)
     # ---- out_proj
     dx1_16 = ops.cast_bf16(dx1)
     if need.get("out_w"):
-        gr["out_w"] = ops.gemm_bf16_wgrad_tokmajor(dx1_16, attn16)
+        gr["out_w"] = ops.gemm_bf16_wgrad_tokmajor(dx1_16, attn16, out=_galloc(alloc, "out_w", (D, D), dev))
     if need.get("out_b"):
-        gr["out_b"] = ops.colsum(dx1)
+        gr["out_b"] = ops.colsum(dx1, out=_galloc(alloc, "out_b", (D,), dev))
     dattn = ops.gemm_bf16(dx1_16, _w16t(c, pre + "out", p.out_w), k=D)                                   # [M, D] fp32
     del dx1_16
     dqkv = ops.attention_bwd(qkv, attn, dattn, lse, B, S, H, causal)                                     # fp32 [M, 3D]
     # ---- qkv projection
     dqkv16 = ops.cast_bf16(dqkv)
     if need.get("qkv_w"):
-        gr["qkv_w"] = ops.gemm_bf16_wgrad_tokmajor(dqkv16, ln1)
+        gr["qkv_w"] = ops.gemm_bf16_wgrad_tokmajor(dqkv16, ln1, out=_galloc(alloc, "qkv_w", (3 * D, D), dev))
     if need.get("qkv_b"):
-        gr["qkv_b"] = ops.colsum(dqkv)
+        gr["qkv_b"] = ops.colsum(dqkv, out=_galloc(alloc, "qkv_b", (3 * D,), dev))
     dln1 = ops.gemm_bf16(dqkv16, _w16t(c, pre + "qkv", p.qkv_w), k=3 * D)
     del dqkv, dqkv16
-    want_ln1 = bool(need.get("ln1_w") or need.get("ln1_b"))
-    dx, dg, db = ops.layernorm_bwd(dln1, x, p.ln1_w, m1, r1, dresidual=dx1, need_param_grads=want_ln1)
-    if want_ln1:
-        gr["ln1_w"], gr["ln1_b"] = dg, db
+    dx = _ln_bwd(dln1, x, p.ln1_w, m1, r1, dx1, bool(need.get("ln1_w") or need.get("ln1_b")), gr, "ln1_w", "ln1_b", alloc)
     return dx, gr
 
 
-def layer_bwd_bf16(dx2, p: LayerParams, c: dict, pre: str, saved, B: int, S: int, H: int, causal: bool, need: Dict[str, bool]):
+def layer_bwd_bf16(dx2, p: LayerParams, c: dict, pre: str, saved, B: int, S: int, H: int, causal: bool, need: Dict[str, bool],
+                   alloc=None):
+    """Backward of layer_fwd_bf16_train.  `alloc(field, shape)`: see _galloc — under data parallelism every parameter
+    gradient (split-K weight gradients, bias column sums, LayerNorm dγ/dβ) is written straight into its bucket slice."""
     x, m1, r1, ln1, qkv, attn, attn16, lse, x1, m2, r2, ln2, h16, g16 = saved
     M = x.shape[0]
     D = x.shape[1]
-    if _tokmajor_wgrads(M, D, g16.shape[1]):
-        return layer_bwd_bf16_tokmajor(dx2, p, c, pre, saved, B, S, H, causal, need)
+    I = g16.shape[1]
+    dev = x.device
+    if _tokmajor_wgrads(M, D, I):
+        return layer_bwd_bf16_tokmajor(dx2, p, c, pre, saved, B, S, H, causal, need, alloc)
     gr: Dict[str, torch.Tensor] = {}
     # ---- fc2
     dx2T, dx2_16 = ops.transpose_bf16(dx2, want_copy=True)
     if need.get("fc2_w"):
-        gr["fc2_w"] = _wgrad_bf16(dx2T, ops.transpose_bf16(g16), M, True)
+        gr["fc2_w"] = ops.gemm_bf16_wgrad(dx2T, ops.transpose_bf16(g16), M, out=_galloc(alloc, "fc2_w", (D, I), dev))
     if need.get("fc2_b"):
-        gr["fc2_b"] = ops.colsum(dx2)
+        gr["fc2_b"] = ops.colsum(dx2, out=_galloc(alloc, "fc2_b", (D,), dev))
     dh16 = ops.gemm_bf16(dx2_16, _w16t(c, pre + "fc2", p.fc2_w), k=D, dgelu_of=h16, out_bf16=True)       # [M, I]
     del dx2T, dx2_16
     # ---- fc1
     dhT = ops.transpose_bf16(dh16)
     if need.get("fc1_w"):
-        gr["fc1_w"] = _wgrad_bf16(dhT, ops.transpose_bf16(ln2), M, True)
+        gr["fc1_w"] = ops.gemm_bf16_wgrad(dhT, ops.transpose_bf16(ln2), M, out=_galloc(alloc, "fc1_w", (I, D), dev))
     if need.get("fc1_b"):
-        gr["fc1_b"] = ops.rowsum_bf16(dhT, M)
+        gr["fc1_b"] = ops.rowsum_bf16(dhT, M, out=_galloc(alloc, "fc1_b", (I,), dev))
     dln2 = ops.gemm_bf16(dh16, _w16t(c, pre + "fc1", p.fc1_w), k=dh16.shape[1])                          # [M, D] fp32
     del dh16, dhT
-    want_ln2 = bool(need.get("ln2_w") or need.get("ln2_b"))
-    dx1, dg, db = ops.layernorm_bwd(dln2, x1, p.ln2_w, m2, r2, dresidual=dx2, need_param_grads=want_ln2)
-    if want_ln2:
-        gr["ln2_w"], gr["ln2_b"] = dg, db
+    dx1 = _ln_bwd(dln2, x1, p.ln2_w, m2, r2, dx2, bool(need.get("ln2_w") or need.get("ln2_b")), gr, "ln2_w", "ln2_b", alloc)
     # ---- out_proj
     dx1T, dx1_16 = ops.transpose_bf16(dx1, want_copy=True)
     if need.get("out_w"):
-        gr["out_w"] = _wgrad_bf16(dx1T, ops.transpose_bf16(attn16), M, True)
+        gr["out_w"] = ops.gemm_bf16_wgrad(dx1T, ops.transpose_bf16(attn16), M, out=_galloc(alloc, "out_w", (D, D), dev))
     if need.get("out_b"):
-        gr["out_b"] = ops.colsum(dx1)
+        gr["out_b"] = ops.colsum(dx1, out=_galloc(alloc, "out_b", (D,), dev))
     dattn = ops.gemm_bf16(dx1_16, _w16t(c, pre + "out", p.out_w), k=D)                                   # [M, D] fp32
     del dx1T, dx1_16
     dqkv = ops.attention_bwd(qkv, attn, dattn, lse, B, S, H, causal)                                     # fp32 [M, 3D]
     # ---- qkv projection
     dqkvT, dqkv16 = ops.transpose_bf16(dqkv, want_copy=True)
     if need.get("qkv_w"):
-        gr["qkv_w"] = _wgrad_bf16(dqkvT, ops.transpose_bf16(ln1), M, True)
+        gr["qkv_w"] = ops.gemm_bf16_wgrad(dqkvT, ops.transpose_bf16(ln1), M, out=_galloc(alloc, "qkv_w", (3 * D, D), dev))
     if need.get("qkv_b"):
-        gr["qkv_b"] = ops.colsum(dqkv)
+        gr["qkv_b"] = ops.colsum(dqkv, out=_galloc(alloc, "qkv_b", (3 * D,), dev))
     dln1 = ops.gemm_bf16(dqkv16, _w16t(c, pre + "qkv", p.qkv_w), k=3 * D)
     del dqkv, dqkvT, dqkv16
-    want_ln1 = bool(need.get("ln1_w") or need.get("ln1_b"))
-    dx, dg, db = ops.layernorm_bwd(dln1, x, p.ln1_w, m1, r1, dresidual=dx1, need_param_grads=want_ln1)
-    if want_ln1:
-        gr["ln1_w"], gr["ln1_b"] = dg, db
+    dx = _ln_bwd(dln1, x, p.ln1_w, m1, r1, dx1, bool(need.get("ln1_w") or need.get("ln1_b")), gr, "ln1_w", "ln1_b", alloc)
     return dx, gr
 
 
@@ -504,8 +517,9 @@ def vision_fwd_bf16_train(p: VisionParams, pixel_values: torch.Tensor, cfg, cach
     return out, (cols, emb, m0, r0, saved_layers, cls_tok, mp, rp, pooled)
 
 
-def vision_bwd_bf16(p: VisionParams, saved, d_out: torch.Tensor, cfg, need: List[bool], cache: dict, on_ready=None):
-    """Backward of vision_fwd_bf16_train; same contract as vision_bwd."""
+def vision_bwd_bf16(p: VisionParams, saved, d_out: torch.Tensor, cfg, need: List[bool], cache: dict, on_ready=None, alloc=None):
+    """Backward of vision_fwd_bf16_train; same contract as vision_bwd (`on_ready` per gradient group, `alloc` naming the
+    tensor each parameter gradient is written into)."""
     v = cfg
     cols, emb, m0, r0, saved_layers, cls_tok, mp, rp, pooled = saved
     B = cls_tok.shape[0]
@@ -513,13 +527,12 @@ def vision_bwd_bf16(p: VisionParams, saved, d_out: torch.Tensor, cfg, need: List
     names = p.names()
     needd = dict(zip(names, need))
     grads: Dict[str, Optional[torch.Tensor]] = {n: None for n in names}
+    dev = d_out.device
     if needd["proj_w"]:
-        grads["proj_w"] = ops.gemm(d_out, pooled, ops.LAYOUT_TN)
+        grads["proj_w"] = ops.gemm(d_out, pooled, ops.LAYOUT_TN, out=_galloc(alloc, "proj_w", tuple(p.proj_w.shape), dev))
     dpooled = ops.gemm(d_out, p.proj_w, ops.LAYOUT_NN)
-    want = needd["post_w"] or needd["post_b"]
-    dcls, dg, db = ops.layernorm_bwd(dpooled, cls_tok, p.post_w, mp, rp, need_param_grads=want)
-    if want:
-        grads["post_w"], grads["post_b"] = dg, db
+    dcls = _ln_bwd(dpooled, cls_tok, p.post_w, mp, rp, None, bool(needd["post_w"] or needd["post_b"]), grads, "post_w", "post_b",
+                   alloc)
     if on_ready is not None:
         on_ready({n: grads[n] for n in VisionParams.TAIL if grads[n] is not None})
     lowest = None
@@ -532,26 +545,27 @@ def vision_bwd_bf16(p: VisionParams, saved, d_out: torch.Tensor, cfg, need: List
     dx = ops.scatter_rows(dcls, None, B, S, D)
     for i in range(len(p.layers) - 1, max(lowest, 0) - 1, -1):
         lneed = {f: needd[f"layers.{i}.{f}"] for f in LayerParams.FIELDS}
-        dx, gr = layer_bwd_bf16(dx, p.layers[i], cache, f"v{i}.", saved_layers[i], B, S, H, False, lneed)
+        lalloc = None if alloc is None else (lambda f, shape, i=i: alloc(f"layers.{i}.{f}", shape))
+        dx, gr = layer_bwd_bf16(dx, p.layers[i], cache, f"v{i}.", saved_layers[i], B, S, H, False, lneed, lalloc)
         saved_layers[i] = None
         for f, t in gr.items():
             grads[f"layers.{i}.{f}"] = t
         if on_ready is not None:
             on_ready({f"layers.{i}.{f}": t for f, t in gr.items()})
     if lowest < 0:
-        want = needd["pre_w"] or needd["pre_b"]
-        demb, dg, db = ops.layernorm_bwd(dx, emb, p.pre_w, m0, r0, need_param_grads=want)
-        if want:
-            grads["pre_w"], grads["pre_b"] = dg, db
+        demb = _ln_bwd(dx, emb, p.pre_w, m0, r0, None, bool(needd["pre_w"] or needd["pre_b"]), grads, "pre_w", "pre_b", alloc)
         if needd["pos"] or needd["class_embedding"]:
-            dpos = ops.colsum(demb.view(B, S * D))
+            dpos = ops.colsum(demb.view(B, S * D), out=(_galloc(alloc, "pos", (S * D,), dev) if needd["pos"] else None))
             if needd["pos"]:
                 grads["pos"] = dpos.view(S, D)
             if needd["class_embedding"]:
-                grads["class_embedding"] = dpos[:D].clone()
+                ce = _galloc(alloc, "class_embedding", (D,), dev)
+                ce.copy_(dpos[:D])
+                grads["class_embedding"] = ce
         if needd["patch_w"]:
             dpatch = ops.vision_assemble_bwd(demb, B, S, D)
-            grads["patch_w"] = ops.gemm(dpatch, cols, ops.LAYOUT_TN).view_as(p.patch_w)
+            pw = _galloc(alloc, "patch_w", (D, p.patch_w.numel() // D), dev)
+            grads["patch_w"] = ops.gemm(dpatch, cols, ops.LAYOUT_TN, out=pw).view_as(p.patch_w)
         if on_ready is not None:
             on_ready({n: grads[n] for n in VisionParams.HEAD if grads[n] is not None})
     return [grads[n] for n in names]

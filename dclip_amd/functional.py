@@ -86,17 +86,21 @@ class VisionTowerBf16Fn(torch.autograd.Function):
     def backward(ctx, d_out):
         if ctx.saved is None:
             raise RuntimeError("VisionTowerBf16Fn.backward called twice")
-        on_ready = None
+        on_ready = alloc = None
         owned = set()
-        if _GRAD_READY_HOOK is not None:
+        if _GRAD_READY_HOOK is not None or _GRAD_ALLOC is not None:
             by_name = dict(zip(ctx.p.names(), ctx.param_refs))
+        if _GRAD_READY_HOOK is not None:
             hook = _GRAD_READY_HOOK
 
             def on_ready(named):
                 if hook([(by_name[n], g) for n, g in named.items()]):
                     owned.update(named)
+        if _GRAD_ALLOC is not None:       # bf16 wgrads (split-K reduce), bias sums, LayerNorm dγ/dβ land in the bucket slices
+            galloc = _GRAD_ALLOC
+            alloc = lambda name, shape: galloc(by_name[name], shape)      # noqa: E731
         grads = engine.vision_bwd_bf16(ctx.p, ctx.saved, _c(d_out), ctx.cfg, list(ctx.needs_input_grad[4:]), ctx.cache,
-                                       on_ready)
+                                       on_ready, alloc)
         ctx.saved = None
         if owned:
             grads = [None if n in owned else g for n, g in zip(ctx.p.names(), grads)]

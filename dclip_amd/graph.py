@@ -40,6 +40,11 @@ class GraphedStep:
         torch.cuda.synchronize(dev)
         for p in params:
             p.grad = None
+        # a bf16 student multiplies by bf16 COPIES of its fp32 master weights: the conversion must be inside the graph,
+        # or every replay would use the copies made during the warm-up above (the optimizer runs outside the graph)
+        for m in module.modules():
+            if hasattr(m, "invalidate_bf16_of_trainable"):
+                m.invalidate_bf16_of_trainable()
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.loss = module.training_step(self.static)

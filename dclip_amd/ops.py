@@ -596,13 +596,19 @@ def _bf16(t: torch.Tensor, name: str) -> torch.Tensor:
     return t
 
 
-def cast_bf16(x: torch.Tensor, pad_to: int = 8) -> torch.Tensor:
-    """[rows, cols] fp32 -> bf16 with the row length rounded up to `pad_to` (zero filled)."""
+def cast_bf16(x: torch.Tensor, pad_to: int = 8, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """[rows, cols] fp32 -> bf16 with the row length rounded up to `pad_to` (zero filled).  `out`: refresh an existing
+    copy in place (the persistent bf16 weights of a training tower: a captured HIP graph keeps reading the same buffer)."""
     lib = _lib.load()
     _f32(x, "x")
     rows, cols = x.shape
     ld = (cols + pad_to - 1) // pad_to * pad_to
-    y = torch.empty((rows, ld), dtype=torch.bfloat16, device=x.device)
+    if out is not None:
+        if tuple(_bf16(out, "out").shape) != (rows, ld):
+            raise ValueError(f"cast_bf16: out shape {tuple(out.shape)} != {(rows, ld)}")
+        y = out
+    else:
+        y = torch.empty((rows, ld), dtype=torch.bfloat16, device=x.device)
     _lib.check(lib.dclip_cast_f32_bf16(x.data_ptr(), y.data_ptr(), rows, cols, cols, ld, _stream()), "cast_f32_bf16")
     return y
 
@@ -626,7 +632,7 @@ def layernorm_fwd_bf16(x, gamma, beta, eps: float, save_stats: bool = False):
     return y, mean, rstd
 
 
-def transpose_bf16(x: torch.Tensor, want_copy: bool = False):
+def transpose_bf16(x: torch.Tensor, want_copy: bool = False, out: Optional[torch.Tensor] = None):
     """x [rows, cols] fp32 or bf16 -> x^T [cols, ld] bf16 with ld = rows rounded up to 8 (zero padded): the
     token-contiguous operand of a weight-gradient GEMM.  `want_copy`: also the untransposed bf16 copy [rows, cols]
     (cols % 8 == 0) from the same pass.  Returns xT or (xT, copy)."""
@@ -637,7 +643,12 @@ def transpose_bf16(x: torch.Tensor, want_copy: bool = False):
     if cols % 4:
         raise ValueError("transpose_bf16: cols must be a multiple of 4")
     ld = (rows + 7) // 8 * 8
-    yT = torch.empty((cols, ld), dtype=torch.bfloat16, device=x.device)
+    if out is not None:
+        if tuple(_bf16(out, "out").shape) != (cols, ld):
+            raise ValueError(f"transpose_bf16: out shape {tuple(out.shape)} != {(cols, ld)}")
+        yT = out
+    else:
+        yT = torch.empty((cols, ld), dtype=torch.bfloat16, device=x.device)
     copy = None
     if want_copy:
         if cols % 8:
@@ -648,13 +659,22 @@ def transpose_bf16(x: torch.Tensor, want_copy: bool = False):
     return (yT, copy) if want_copy else yT
 
 
-def rowsum_bf16(x: torch.Tensor, n: Optional[int] = None) -> torch.Tensor:
+def _out_f32(out: Optional[torch.Tensor], shape, device, name: str) -> torch.Tensor:
+    """`out` (a caller-named destination, e.g. a gradient's slice of its all-reduce bucket) checked, or a fresh tensor."""
+    if out is None:
+        return torch.empty(shape, dtype=torch.float32, device=device)
+    if tuple(out.shape) != tuple(shape) or out.dtype != torch.float32 or not out.is_contiguous() or not out.is_cuda:
+        raise ValueError(f"{name}: out must be a contiguous float32 CUDA tensor of shape {tuple(shape)}")
+    return out
+
+
+def rowsum_bf16(x: torch.Tensor, n: Optional[int] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Row sums (fp32) of the first n columns of a bf16 matrix [R, ld]."""
     lib = _lib.load()
     _bf16(x, "x")
     R, ld = x.shape
     n = ld if n is None else n
-    out = torch.empty((R,), dtype=torch.float32, device=x.device)
+    out = _out_f32(out, (R,), x.device, "rowsum_bf16")
     _lib.check(lib.dclip_rowsum_bf16(x.data_ptr(), out.data_ptr(), R, n, ld, _stream()), "rowsum_bf16")
     return out
 
@@ -720,7 +740,8 @@ def gemm_bf16(a: torch.Tensor, w: torch.Tensor, *, n: Optional[int] = None, k: O
     return (out, aux) if save_preact else out
 
 
-def gemm_bf16_wgrad(a: torch.Tensor, w: torch.Tensor, k: int, splits: Optional[int] = None) -> torch.Tensor:
+def gemm_bf16_wgrad(a: torch.Tensor, w: torch.Tensor, k: int, splits: Optional[int] = None,
+                    out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """dW [M, N] fp32 = a[:, :k] @ w[:, :k]^T over bf16 token-contiguous operands (a = dY^T [M, ld], w = X^T [N, ld]):
     split-K when the output has few tiles (deterministic: partials summed in fixed order)."""
     lib = _lib.load()
@@ -729,7 +750,7 @@ def gemm_bf16_wgrad(a: torch.Tensor, w: torch.Tensor, k: int, splits: Optional[i
     N, ldw = w.shape
     if splits is None:
         splits = lib.dclip_gemm_bf16_splitk_plan(M, N, k)
-    out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    out = _out_f32(out, (M, N), a.device, "gemm_bf16_wgrad")
     nbytes = lib.dclip_gemm_bf16_splitk_workspace(M, N, splits)
     ws = _ws.get(nbytes, a.device)
     _lib.check(lib.dclip_gemm_bf16_splitk(a.data_ptr(), w.data_ptr(), out.data_ptr(), M, N, k, lda, ldw, N, splits,
@@ -737,7 +758,7 @@ def gemm_bf16_wgrad(a: torch.Tensor, w: torch.Tensor, k: int, splits: Optional[i
     return out
 
 
-def gemm_bf16_wgrad_tokmajor(dy: torch.Tensor, x: torch.Tensor) -> Optional[torch.Tensor]:
+def gemm_bf16_wgrad_tokmajor(dy: torch.Tensor, x: torch.Tensor, out: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
     """dW [out, in] fp32 = dy^T x from the token-major bf16 operands dy [tokens, out], x [tokens, in] as the backward has
     them (no transposes).  Returns None when the library's token-major form does not apply to the shape (the caller then
     transposes and uses gemm_bf16_wgrad)."""
@@ -750,7 +771,7 @@ def gemm_bf16_wgrad_tokmajor(dy: torch.Tensor, x: torch.Tensor) -> Optional[torc
     splits = lib.dclip_gemm_bf16_wgrad_tokmajor_plan(M, N, K)
     if splits == 0:
         return None
-    out = torch.empty((M, N), dtype=torch.float32, device=dy.device)
+    out = _out_f32(out, (M, N), dy.device, "gemm_bf16_wgrad_tokmajor")
     nbytes = lib.dclip_gemm_bf16_splitk_workspace(M, N, splits)
     ws = _ws.get(nbytes, dy.device)
     _lib.check(lib.dclip_gemm_bf16_wgrad_tokmajor(dy.data_ptr(), x.data_ptr(), out.data_ptr(), M, N, K, M, N, N, splits,
@@ -758,12 +779,12 @@ def gemm_bf16_wgrad_tokmajor(dy: torch.Tensor, x: torch.Tensor) -> Optional[torc
     return out
 
 
-def colsum_bf16(x: torch.Tensor) -> torch.Tensor:
+def colsum_bf16(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Column sums (over the rows = tokens) of a bf16 matrix, fp32 result: a bias gradient from a bf16 dY."""
     lib = _lib.load()
     _bf16(x, "x")
     M, N = x.shape
-    out = torch.empty((N,), dtype=torch.float32, device=x.device)
+    out = _out_f32(out, (N,), x.device, "colsum_bf16")
     nbytes = lib.dclip_colsum_f32_workspace(M, N)
     ws = _ws.get(nbytes, x.device)
     _lib.check(lib.dclip_colsum_bf16(x.data_ptr(), out.data_ptr(), M, N, N, 0, _ptr(ws), nbytes, _stream()), "colsum_bf16")

@@ -209,8 +209,10 @@ def test_bf16_layer_backward_schedules_agree(monkeypatch):
     ids = synth.synth_input_ids(B, cfg.text, seed=3, ragged=True).to(dev)
     t_img = synth.synth_embeddings(B, cfg.projection_dim, seed=1).to(dev)
     grads = []
+    from dclip_amd import engine
     for flag in ("1", "0"):
         monkeypatch.setenv("DCLIP_BF16_WGRAD_TN", flag)
+        engine._TOKMAJOR_PLAN.clear()                                # the schedule choice is cached per (M, D, I)
         m = from_hf_state_dict(cfg, sd, device=dev)
         for p_ in m.text_model.parameters():
             p_.requires_grad = False
@@ -222,3 +224,46 @@ def test_bf16_layer_backward_schedules_agree(monkeypatch):
         a, b = grads[0][n], grads[1][n]
         cos = float((a @ b) / (a.norm() * b.norm() + 1e-30))
         assert cos > 0.999999, (n, cos)
+
+
+def test_bf16_student_under_graph_replay_follows_the_optimizer():
+    """the bf16 weight copies must be refreshed INSIDE the captured step.  Replay, optimizer step,
+    replay — the second replay's loss and gradients equal the eager module's second step (same kernels, same order:
+    bit-identical); before the fix it multiplied by the copies made during the capture's warm-up."""
+    from dclip_amd.CLIP_image_distillation import CLIPImageDistillation
+    from dclip_amd.clip_model import from_hf_state_dict
+    from dclip_amd.graph import GraphedStep
+    from dclip_amd.optim import FusedAdamW
+    dev = torch.device("cuda:0")
+    cfg = dcfg.tiny()
+    B = 6
+
+    def make():
+        student = from_hf_state_dict(cfg, synth.synth_clip_state_dict(cfg, seed=0, gain=3.0), device=dev)
+        hp = argparse.Namespace(learning_rate=1e-2, warmup_steps=0, total_steps=100, train_batch_size=B, eval_batch_size=B)
+        mod = CLIPImageDistillation(hp, student, None, freeze_mode="north_star", student_precision="bf16").to(dev)
+        return mod, FusedAdamW([p for p in mod.parameters() if p.requires_grad], lr=1e-2, max_grad_norm=0.5)
+
+    batch = {"pixel_values": synth.synth_pixel_values(B, cfg.vision, seed=20).to(dev),
+             "input_ids": synth.synth_input_ids(B, cfg.text, seed=21, ragged=True).to(dev),
+             "teacher_image_emb": synth.synth_embeddings(B, cfg.projection_dim, seed=22).to(dev)}
+    (eager, opt_e), (graphed, opt_g) = make(), make()
+    g = GraphedStep(graphed, batch)
+    names = [n for n, p in eager.named_parameters() if p.requires_grad]
+    losses = []
+    for it in range(3):
+        for p in eager.parameters():
+            p.grad = None
+        le = eager.training_step(batch)
+        le.backward()
+        lg = g.step(batch)
+        assert torch.equal(le.detach(), lg.detach()), (it, float(le), float(lg))
+        ge, gg = dict(eager.named_parameters()), dict(graphed.named_parameters())
+        for n in names:
+            assert torch.equal(ge[n].grad, gg[n].grad), (it, n)
+        losses.append(float(le.detach()))
+        opt_e.step()
+        opt_g.step()
+    assert losses[1] != losses[0] and losses[2] != losses[1]          # the updates are visible through the bf16 copies
+    for n in names:
+        assert torch.equal(dict(eager.named_parameters())[n], dict(graphed.named_parameters())[n]), n

@@ -54,6 +54,70 @@ def test_c3_meta_teacher_8_regions_real_size():
     assert _rel(g, p["visual_projection.weight"].grad) < 2e-3
 
 
+def test_c3_as_quoted_bf16_student_bf16_towers_8_regions():
+    """c3 AS BASELINE STATES IT: bf16 student + bf16 teacher towers + 8 ragged regions per image + the meta-teacher
+    inside the step (reference step: training/CLIP_image_distillation.py:594-628, fp32 there).  Gate: loss within 1e-3
+    relative of the fp32 CPU oracle run on the same inputs; printed beside it: cosine of the teacher target against the
+    oracle's, per-tensor gradient cosine of the student's trainable set against the oracle's fp32 gradients."""
+    from dclip_amd.clip_model import from_hf_state_dict
+    from dclip_amd.CLIP_image_distillation import CLIPImageDistillation
+    from dclip_amd.patch_text_aggregation import PatchTextAggregation
+    dev = torch.device("cuda:0")
+    cfg = dcfg.vit_b32()
+    sd = synth.synth_clip_state_dict(cfg, seed=0, gain=3.0)
+    tsd = synth.synth_clip_state_dict(cfg, seed=7, gain=3.0)                     # a separate frozen teacher CLIP, as in bench c3
+    cm = synth.synth_cross_modal_state_dict(cfg.projection_dim, seed=31)
+    student = from_hf_state_dict(cfg, sd, device=dev)
+    teacher_clip = from_hf_state_dict(cfg, tsd, device=dev)
+    for p_ in teacher_clip.parameters():
+        p_.requires_grad = False
+    teacher = PatchTextAggregation(embed_dim=512, num_heads=8, clip_model=teacher_clip, tower_precision="bf16")
+    teacher.load_state_dict({f"cross_modal_attention.{k}": v for k, v in cm.items()})
+    hp = argparse.Namespace(learning_rate=1e-5, warmup_steps=0, total_steps=10, train_batch_size=4, eval_batch_size=4)
+    mod = CLIPImageDistillation(hp, student, None, teacher=teacher.to(dev), freeze_mode="north_star",
+                                student_precision="bf16").to(dev)
+    B, R = 4, 8
+    pix = synth.synth_pixel_values(B, cfg.vision, seed=0)
+    regions = synth.synth_regions(B, R, cfg.vision, seed=2)
+    counts = torch.tensor([8, 5, 1, 7])
+    ids = synth.synth_input_ids(B, cfg.text, seed=3, ragged=True, min_len=12)
+    loss = mod.training_step({"pixel_values": pix, "input_ids": ids, "regions": regions, "region_counts": counts})
+    loss.backward()
+    with torch.no_grad():                                                        # the fp32 oracle of the same step
+        toks, n_tok, sent = O.teacher_token_embeddings(tsd, ids, cfg.text)
+        embs = [O.vision_tower(tsd, regions[b, :int(counts[b])], cfg.vision) for b in range(B)]
+        t_img = O.global_embedding(cm, toks, O.pad_regions(embs, 512), heads=8)
+        got_t = mod.teacher.compute_global_embedding_tensors(regions.to(dev), ids.to(dev), counts).float().cpu()
+    t_cos = float(torch.nn.functional.cosine_similarity(got_t, t_img, dim=1).min())
+    p = {k: v.clone().requires_grad_(v.is_floating_point() and k.startswith("vision") or k == "visual_projection.weight")
+         for k, v in sd.items()}
+    ref = O.distill_step(p, cfg, pix, ids, t_img, sent)
+    ref["loss"].backward()
+    got, want = float(loss.detach()), float(ref["loss"])
+    named = dict(mod.student.state_dict(keep_vars=True))
+    cos = {}
+    for k, v in p.items():
+        if v.grad is None or "self_attn" in k and ("q_proj" in k or "k_proj" in k or "v_proj" in k):
+            continue
+        g = named[k].grad
+        if g is None:
+            continue
+        a, b = g.double().cpu().reshape(-1), v.grad.double().reshape(-1)
+        cos[k] = float(a @ b / (a.norm() * b.norm()).clamp_min(1e-30))
+    for i in (0, 11):                                                            # fused q/k/v in memory: compare the fusion
+        qkv = mod.student.vision_model.encoder.layers[i].self_attn.qkv_proj.weight.grad.double().cpu().reshape(-1)
+        refq = torch.cat([p[f"vision_model.encoder.layers.{i}.self_attn.{n}.weight"].grad for n in ("q_proj", "k_proj", "v_proj")])
+        refq = refq.double().reshape(-1)
+        cos[f"layers.{i}.qkv_proj.weight"] = float(qkv @ refq / (qkv.norm() * refq.norm()).clamp_min(1e-30))
+    worst = sorted(cos.items(), key=lambda kv: kv[1])[:3]
+    print(f"c3 as quoted (bf16 student, bf16 teacher towers, 8 ragged regions, B={B}): loss {got:.6f} vs fp32 oracle {want:.6f} "
+          f"(rel {abs(got - want) / abs(want):.2e}); teacher-target min cosine {t_cos:.6f}; gradient cosine over {len(cos)} tensors "
+          f"min {min(cos.values()):.5f} median {sorted(cos.values())[len(cos) // 2]:.5f}; worst {worst}")
+    assert abs(got - want) <= 1e-3 * abs(want)
+    assert t_cos > 0.9995
+    assert min(cos.values()) > 0.99
+
+
 def test_c4_vit_b16_step():
     """c4's per-GPU work at small batch: ViT-B/16 (S = 197: multi-tile attention) distill step."""
     from dclip_amd.clip_model import from_hf_state_dict

@@ -1,0 +1,175 @@
+"""Data parallelism BEHIND THE ENTRY POINTS (north_star: "keeping the CLIP_image_distillation / train_contrastive_teacher
+entry points"; the reference is single-GPU, training/CLIP_image_distill_training.py:36-45,
+training/train_contrastive_teacher.py:333-362): two ranks share the one GPU of the test box over gloo, run the real
+kernels through `lightning_lite.Trainer.fit` / `train_contrastive_teacher.main`, and end where ONE process ends on the
+concatenated batches."""
+import argparse
+import glob
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from dclip_amd import config as dcfg, synth
+
+pytestmark = pytest.mark.gpu
+LR, ACCUM, GROUPS, B = 1e-3, 2, 6, 4          # 6 rank groups at accumulate 2 = 3 optimizer steps
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _student_module(dev, precision):
+    from dclip_amd.clip_model import from_hf_state_dict
+    from dclip_amd.CLIP_image_distillation import CLIPImageDistillation
+    from dclip_amd.patch_text_aggregation import PatchTextAggregation
+    cfg = dcfg.tiny()
+    student = from_hf_state_dict(cfg, synth.synth_clip_state_dict(cfg, seed=7, gain=4.0), device=dev)
+    teacher = PatchTextAggregation(embed_dim=cfg.projection_dim, num_heads=1, clip_model=student).to(dev)
+    hp = argparse.Namespace(learning_rate=LR, warmup_steps=0, total_steps=100, train_batch_size=B, eval_batch_size=B)
+    return cfg, CLIPImageDistillation(hp, student, None, teacher=teacher, freeze_mode="north_star",
+                                      student_precision=precision).to(dev)
+
+
+def _student_batches(cfg, n, b):
+    return [{"pixel_values": synth.synth_pixel_values(b, cfg.vision, seed=10 + i),
+             "input_ids": synth.synth_input_ids(b, cfg.text, seed=40 + i, ragged=True),
+             "teacher_image_emb": synth.synth_embeddings(b, cfg.projection_dim, seed=70 + i),
+             "teacher_text_emb": synth.synth_embeddings(b, cfg.projection_dim, seed=90 + i)} for i in range(n)]
+
+
+def _trainable_state(mod):
+    return {n: p.detach().float().cpu().clone() for n, p in mod.named_parameters() if p.requires_grad}
+
+
+def _fit_worker(rank, world, port, ckpt_dir, precision, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK="0")
+    from dclip_amd.lightning_lite import Trainer
+    dev = torch.device("cuda:0")
+    cfg, mod = _student_module(dev, precision)
+    tr = Trainer(max_epochs=1, gradient_clip_val=0.5, accumulate_grad_batches=ACCUM, checkpoint_dir=ckpt_dir,
+                 devices=world, dist_backend="gloo", bucket_mb=0.05)
+    tr.fit(mod, _student_batches(cfg, GROUPS * world + 1, B))        # the odd batch out is dropped on every rank
+    torch.cuda.synchronize()
+    st = tr.grad_sync.stats()
+    out[rank] = dict(params=_trainable_state(mod), step=mod.global_step, saved=len(tr.saved), stats=st,
+                     train_loss=mod.logged("train_loss"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_two_rank_trainer_fit_equals_single_process(tmp_path, precision):
+    from dclip_amd.lightning_lite import Trainer
+    world = 2
+    out = mp.Manager().dict()
+    mp.spawn(_fit_worker, args=(world, _free_port(), str(tmp_path / "dp"), precision, out), nprocs=world, join=True)
+    dev = torch.device("cuda:0")
+    cfg, ref = _student_module(dev, precision)
+    start = _trainable_state(ref)
+    per_gpu = _student_batches(cfg, GROUPS * world + 1, B)
+    cat = [{k: torch.cat([per_gpu[world * j + r][k] for r in range(world)]) for k in per_gpu[0]} for j in range(GROUPS)]
+    tr = Trainer(max_epochs=1, gradient_clip_val=0.5, accumulate_grad_batches=ACCUM, checkpoint_dir=str(tmp_path / "one"))
+    tr.fit(ref, cat)
+    want = _trainable_state(ref)
+    steps = GROUPS // ACCUM
+    assert ref.global_step == steps
+    moved = max(float((want[n] - start[n]).abs().max()) for n in want)
+    assert moved > 0.5 * LR                                          # the run really updated the parameters
+    for r in range(world):
+        o = out[r]
+        assert o["step"] == steps
+        worst = max(float((o["params"][n] - want[n]).abs().max()) for n in want)
+        rel = max(float((o["params"][n] - want[n]).abs().max() / want[n].abs().max().clamp_min(1e-30)) for n in want)
+        print(f"[{precision}] rank {r}: max |param - single-process| {worst:.3e} (rel to tensor max {rel:.3e}); "
+              f"largest update {moved:.3e}; stats {o['stats']}")
+        # Adam turns a gradient into an update of size ~lr whatever its magnitude: summation-order noise on near-zero
+        # gradient elements shows up as a small fraction of lr.  A wrong scale / missing rank would show as ~lr * steps.
+        assert worst < 0.02 * LR * steps, worst
+        assert abs(o["train_loss"] - ref.logged("train_loss")) < 1e-4 * abs(ref.logged("train_loss"))
+        # hooks only on the boundary micro-batch, every gradient of the hooked tower produced in its bucket slice
+        assert o["stats"]["grad_tensors_copied_per_step"] == 0 and o["stats"]["grad_tensors_written_in_place_per_step"] >= 30, o["stats"]
+    for n in want:                                                   # the replicas never diverge
+        assert torch.equal(out[0]["params"][n], out[1]["params"][n]), n
+    assert out[0]["saved"] == 1 and out[1]["saved"] == 0
+    assert len(glob.glob(str(tmp_path / "dp" / "*.ckpt"))) == 1
+
+
+def _teacher(dev):
+    from dclip_amd.clip_model import from_hf_state_dict
+    from dclip_amd.patch_text_aggregation import PatchTextAggregation
+    cfg = dcfg.tiny()
+    clip = from_hf_state_dict(cfg, synth.synth_clip_state_dict(cfg, seed=7, gain=4.0), device=dev)
+    t = PatchTextAggregation(embed_dim=cfg.projection_dim, num_heads=1, clip_model=clip).to(dev)
+    t.cross_modal_attention.load_state_dict(
+        {k: v.to(dev) for k, v in synth.synth_cross_modal_state_dict(cfg.projection_dim, seed=31).items()})
+    return cfg, t
+
+
+def _teacher_batches(cfg, seed0, n, b):
+    counts = [3, 2, 1, 3, 0, 2, 3, 1]
+    return [{"regions": synth.synth_regions(b, 3, cfg.vision, seed=seed0 + i),
+             "input_ids": synth.synth_input_ids(b, cfg.text, seed=50 + seed0 + i, ragged=True, min_len=4),
+             "region_counts": torch.tensor(counts[:b]),
+             # ONE padding length for every shard and for the concatenation (the block attends to padded rows, N4)
+             "max_tokens": cfg.text.max_position_embeddings - 2} for i in range(n)]
+
+
+def _teacher_worker(rank, world, port, path, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK="0", DCLIP_DIST_BACKEND="gloo")
+    from dclip_amd import train_contrastive_teacher as T
+    dev = torch.device("cuda:0")
+    cfg, teacher = _teacher(dev)
+    args = argparse.Namespace(train_file=None, val_file=None, batch_size=4, gradient_accumulation=8, learning_rate=2e-3,
+                              epochs=2, output_path=path)
+    res = T.main(args, teacher=teacher, train_batches=_teacher_batches(cfg, 0, 3 * world, 4),
+                 val_batches=_teacher_batches(cfg, 100, world, 4))
+    torch.cuda.synchronize()
+    out[rank] = dict(sd={k: v.detach().cpu().clone() for k, v in teacher.state_dict().items()}, hist=res["history"])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_teacher_trainer_equals_single_process(tmp_path):
+    from dclip_amd import train_contrastive_teacher as T
+    world = 2
+    out = mp.Manager().dict()
+    path = str(tmp_path / "dp" / "contrastive_teacher.pth")
+    mp.spawn(_teacher_worker, args=(world, _free_port(), path, out), nprocs=world, join=True)
+    dev = torch.device("cuda:0")
+    cfg, teacher = _teacher(dev)
+
+    def cat(bs):
+        res = []
+        for j in range(len(bs) // world):
+            grp = bs[world * j: world * (j + 1)]
+            res.append({"regions": torch.cat([g["regions"] for g in grp]), "input_ids": torch.cat([g["input_ids"] for g in grp]),
+                        "region_counts": torch.cat([g["region_counts"] for g in grp]), "max_tokens": grp[0]["max_tokens"]})
+        return res
+
+    args = argparse.Namespace(train_file=None, val_file=None, batch_size=8, gradient_accumulation=8, learning_rate=2e-3,
+                              epochs=2, output_path=str(tmp_path / "one" / "contrastive_teacher.pth"))
+    res = T.main(args, teacher=teacher, train_batches=cat(_teacher_batches(cfg, 0, 3 * world, 4)),
+                 val_batches=cat(_teacher_batches(cfg, 100, world, 4)))
+    want = {k: v.detach().cpu() for k, v in teacher.state_dict().items()}
+    steps = 3 * 2
+    for r in range(world):
+        worst = max(float((out[r]["sd"][k] - want[k]).abs().max()) for k in want)
+        print(f"teacher trainer rank {r}: max |param - single-process| {worst:.3e}; history {out[r]['hist']} vs {res['history']}")
+        assert worst < 0.02 * 2e-3 * steps, worst
+        for (a, av), (b, bv) in zip(out[r]["hist"], res["history"]):
+            assert abs(a - b) < 1e-4 * abs(b) and abs(av - bv) < 1e-4 * abs(bv)
+    files = sorted(os.path.basename(f) for f in glob.glob(str(tmp_path / "dp" / "*.pth")))
+    assert "contrastive_teacher.pth" in files and sum("_epoch" in f for f in files) == 2        # rank 0 alone wrote them
+    sd = torch.load(path, weights_only=True)
+    assert len(sd) == 12

@@ -249,7 +249,11 @@ def test_normalize_rows(dev):
 
 
 @pytest.mark.parametrize("Bl,Bg,P,offset", [(8, 8, 512, 0), (37, 37, 768, 0), (256, 256, 512, 0), (64, 256, 512, 128),
-                                            (3, 5, 64, 2), (200, 1000, 512, 400)])
+                                            (3, 5, 64, 2), (200, 1000, 512, 400),
+                                            # the shapes the 8-GPU configs produce per rank (BASELINE c5: 512 local x 4096
+                                            # global negatives, rank 3's offset; c4: 128 x 1024): other tile counts, other
+                                            # part_m / part_s slab sizes, the 8 MB W workspace
+                                            (512, 4096, 512, 1536), (128, 1024, 512, 384)])
 def test_contrastive_lse_and_grad(dev, Bl, Bg, P, offset):
     from dclip_amd import ops
     inv_t = 20.0
