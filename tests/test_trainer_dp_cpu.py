@@ -85,7 +85,9 @@ def _make_module(group=None):
             return loss
 
         def configure_optimizers(self):
-            return [torch.optim.AdamW([p for p in self.parameters() if p.requires_grad], lr=0.05)], []
+            # plain SGD on purpose: Adam and norm clipping are invariant to the SCALE of the gradient, and the scale
+            # (1 / accumulate, mean over the global batch, SUM over ranks) is exactly what this test must pin
+            return [torch.optim.SGD([p for p in self.parameters() if p.requires_grad], lr=0.05)], []
 
     return Toy()
 
@@ -123,7 +125,7 @@ def _worker(rank, world, port, ckpt_dir, out):
 
     ddist.GradSync._launch = counting_launch
     mod = _make_module()
-    tr = Trainer(max_epochs=1, gradient_clip_val=0.5, accumulate_grad_batches=2, checkpoint_dir=ckpt_dir,
+    tr = Trainer(max_epochs=1, gradient_clip_val=None, accumulate_grad_batches=2, checkpoint_dir=ckpt_dir,
                  devices=world, dist_backend="gloo", bucket_mb=0.0001)          # tiny buckets: every tensor its own
     # 13 per-GPU batches: 6 full rank groups (= 3 optimizer steps at accumulate 2); the 13th is dropped on every rank
     tr.fit(mod, _batches(13, 4))
@@ -144,7 +146,7 @@ def test_two_rank_fit_equals_single_process_fit_on_concatenated_batches(tmp_path
     per_gpu = _batches(13, 4)
     cat = [{k: torch.cat([per_gpu[2 * j][k], per_gpu[2 * j + 1][k]]) for k in per_gpu[0]} for j in range(6)]
     ref = _make_module()
-    tr = Trainer(max_epochs=1, gradient_clip_val=0.5, accumulate_grad_batches=2, checkpoint_dir=str(tmp_path / "one"))
+    tr = Trainer(max_epochs=1, gradient_clip_val=None, accumulate_grad_batches=2, checkpoint_dir=str(tmp_path / "one"))
     tr.fit(ref, cat)
     assert ref.global_step == 3
     for r in range(world):

@@ -4,8 +4,8 @@ set -e -o pipefail
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/r03a
 rm -rf $O && mkdir -p $O
-timeout -k 10 900 python3 -m pytest tests/test_entrypoints_dp_gpu.py tests/test_dist_gpu.py tests/test_bf16_train_gpu.py tests/test_configs_gpu.py "tests/test_ops_gpu.py::test_contrastive_lse_and_grad" tests/test_bf16_gpu.py::test_bf16_weight_cache_follows_the_fused_optimizer -x -q -s -m gpu > $O/tests.log 2>&1 || { tail -40 $O/tests.log; exit 1; }
-tail -3 $O/tests.log
+timeout -k 10 900 python3 -m pytest tests/test_entrypoints_dp_gpu.py tests/test_dist_gpu.py tests/test_bf16_train_gpu.py tests/test_configs_gpu.py "tests/test_ops_gpu.py::test_contrastive_lse_and_grad" tests/test_bf16_gpu.py::test_bf16_weight_cache_follows_the_fused_optimizer -q -s -m gpu > $O/tests.log 2>&1 && TRC=0 || TRC=$?
+grep -E "^(FAILED|ERROR)|passed|failed" $O/tests.log | tail -15 || true
 C3="--workload c3 --student-precision bf16 --tower-precision bf16 --eager --no-cpu-baseline --no-extra-legs"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/c3stats -o s -- python3 bench.py $C3 --steps 4 --warmup 1 > $O/c3stats.log 2>&1
 echo "c3 stats done"
@@ -21,5 +21,6 @@ tail -c 600 $O/bench_c3.json
 DCLIP_DIST_BACKEND=gloo timeout -k 10 420 python3 bench.py --gpus 4 --batch 16 --steps 6 --warmup 2 > $O/gloo4.json 2> $O/gloo4.err || { echo "gloo4 rc=$?"; tail -30 $O/gloo4.err; exit 1; }
 cat $O/gloo4.json | cut -c1-1200
 grep -c "timed step" $O/gloo4.err
+echo "tests rc=$TRC"
 # keep the big counter CSVs out of the merge-back budget
 find $O -name "*counter_collection.csv" -size +20M -delete
