@@ -171,6 +171,104 @@ def cpu_baseline(seconds: float = 12.0, regime: str = "north_star"):
                       f"(oracle/dclip_oracle.py, torch {torch.__version__} CPU)"}
 
 
+def build_workload(workload, model, teacher_model, batch_size, regions, student_precision, tower_precision, dev, group, rank):
+    """The distillation module of one BASELINE config on synthetic inputs resident in HBM -> (module, student config, teacher
+    config or None, batch).  c2: teacher image embedding given.  c3 / c5: the meta-teacher runs inside the step on `regions`
+    crops per image through a separate frozen teacher CLIP."""
+    from dclip_amd.clip_model import from_hf_state_dict
+    from dclip_amd.CLIP_image_distillation import CLIPImageDistillation
+    from dclip_amd.patch_text_aggregation import PatchTextAggregation
+    meta = workload in ("c3", "c5")
+    cfg = dcfg.NAMED[model]()
+    student = from_hf_state_dict(cfg, synth.synth_clip_state_dict(cfg, seed=0), device=dev)   # same init on all ranks
+    tcfg = None
+    if meta:
+        tcfg = dcfg.NAMED[teacher_model or model]()
+        teacher_clip = from_hf_state_dict(tcfg, synth.synth_clip_state_dict(tcfg, seed=7), device=dev)
+        for p_ in teacher_clip.parameters():
+            p_.requires_grad = False
+        E = tcfg.projection_dim               # a wider teacher is bridged to the student inside the module (c5)
+        teacher = PatchTextAggregation(embed_dim=E, num_heads=E // 64, clip_model=teacher_clip,
+                                       tower_precision=tower_precision).to(dev)
+    else:
+        teacher = PatchTextAggregation(embed_dim=cfg.projection_dim, num_heads=cfg.projection_dim // 64,
+                                       clip_model=student).to(dev)
+    # the cross-modal block too from a seeded state (its constructor draws from the process's default RNG): the same frozen
+    # teacher in every run and on every rank
+    teacher.cross_modal_attention.load_state_dict(
+        {k: v.to(dev) for k, v in synth.synth_cross_modal_state_dict(teacher.embed_dim, seed=31).items()})
+    hp = argparse.Namespace(learning_rate=1e-6, warmup_steps=0, total_steps=10 ** 6, train_batch_size=batch_size,
+                            eval_batch_size=batch_size)
+    module = CLIPImageDistillation(hp, student, None, teacher=teacher, freeze_mode="north_star",
+                                   process_group=group, student_precision=student_precision).to(dev)
+    batch = {                                                     # resident in HBM before the timed region
+        "pixel_values": synth.synth_pixel_values(batch_size, cfg.vision, seed=rank).to(dev),
+        "input_ids": synth.synth_input_ids(batch_size, cfg.text, seed=100 + rank).to(dev),
+    }
+    if meta:
+        batch["regions"] = synth.synth_regions(batch_size, regions, tcfg.vision, seed=2000 + rank).to(dev)
+    else:
+        batch["teacher_image_emb"] = synth.synth_embeddings(batch_size, cfg.projection_dim, seed=1000 + rank).to(dev)
+    return module, cfg, tcfg, batch
+
+
+def meta_teacher_flops(cfg, tcfg, B, R, T) -> float:
+    """R frozen region forwards + the teacher's own text forward + cross-attention (+ the bridge), per step."""
+    E = tcfg.projection_dim
+    return B * (R * (vision_fwd_flops(tcfg.vision) + 2.0 * tcfg.vision.hidden_size * E)
+                + text_fwd_flops(tcfg.text, T) + 2.0 * T * tcfg.text.hidden_size * E
+                + 8.0 * E * E * (T + R) + 8.0 * T * R * E
+                + (4.0 * E * cfg.projection_dim if E != cfg.projection_dim else 0.0))
+
+
+def extra_config_c3(dev, timer, steps: int = 5, warmup: int = 2):
+    """BASELINE config c3 AS QUOTED (ViT-B/32 student in bf16 + meta-teacher on 8 region crops per image through frozen bf16
+    towers, 256 pairs) timed for a few steps AFTER the contract's timed region, so that the driver's record carries the
+    bf16 configs' figures too (fwd + bwd + clip + AdamW, eager launches, HIP events on every bf16 GEMM launch)."""
+    from dclip_amd import optim
+    B, R = 256, 8
+    module, cfg, tcfg, batch = build_workload("c3", "ViT-B/32", "ViT-B/32", B, R, "bf16", "bf16", dev, None, 0)
+    T = cfg.text.max_position_embeddings
+    trainable = [p for p in module.parameters() if p.requires_grad]
+    opt = optim.FusedAdamW(trainable, lr=1e-6, max_grad_norm=0.5)
+
+    def one():
+        loss = module.training_step(batch)
+        loss.backward()
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+        return loss.detach()
+
+    for _ in range(warmup):
+        one()
+    timer.records16.clear()
+    timer.enabled = True
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        last = one()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    timer.enabled = False
+    f16, ms16, n16 = timer.summary(bf16=True)
+    ms = el * 1e3 / steps
+    floor_ms = (step_flops_per_image(cfg, T) * B + meta_teacher_flops(cfg, tcfg, B, R, T)) / 2500.0 / 1e9
+    out = {"workload": "BASELINE config c3 as quoted: ViT-B/32 student bf16 (fp32 masters) + meta-teacher in the step (8 region "
+                       "crops/img through a frozen ViT-B/32 tower, bf16 GEMM inputs), bs=256, fwd+bwd + clip-norm 0.5 + AdamW, "
+                       "eager launches, HIP events around every bf16 GEMM launch",
+           "value": round(B * steps / el, 2), "unit": "images/s", "ms_per_step": round(ms, 3), "steps": steps, "warmup": warmup,
+           "dtype": "bf16", "loss": float(last),
+           "roofline_bf16": {"bound": "mfma", "kernel": "gemm_bf16_pp_kernel (v_mfma_f32_16x16x32_bf16)",
+                             "achieved": round(f16 / (ms16 * 1e-3) / 1e12, 2) if ms16 else None, "peak": 2500.0, "unit": "TFLOP/s",
+                             "frac": round(f16 / (ms16 * 1e-3) / 1e12 / 2500.0, 4) if ms16 else None,
+                             "launches_per_step": n16 // steps, "gemm_ms_per_step": round(ms16 / steps, 3)},
+           "roofline_step": {"bound": "mfma", "unit": "ms", "floor_ms": round(floor_ms, 3), "frac": round(floor_ms / ms, 4),
+                             "peak_tflops": 2500.0}}
+    del module, opt, batch
+    torch.cuda.empty_cache()
+    return out
+
+
 def self_launch(n: int) -> int:
     """Run `python -m torch.distributed.run --nnodes=1 --nproc-per-node n bench.py <same args>` as a child process,
     relay rank 0's JSON line (the only thing the ranks print on stdout) and return the child's exit code."""
@@ -275,33 +373,10 @@ def main():
         if step_log:
             print(f"[rank {rank} +{time.perf_counter() - t_start:7.2f}s] {msg}", file=sys.stderr, flush=True)
 
-    from dclip_amd.clip_model import from_hf_state_dict
-    from dclip_amd.CLIP_image_distillation import CLIPImageDistillation
-    from dclip_amd.patch_text_aggregation import PatchTextAggregation
     from dclip_amd import optim
-
-    cfg = dcfg.NAMED[args.model]()
-    student = from_hf_state_dict(cfg, synth.synth_clip_state_dict(cfg, seed=0), device=dev)   # same init on all ranks
-    tcfg = None
-    if meta:
-        tcfg = dcfg.NAMED[args.teacher_model or args.model]()
-        teacher_clip = from_hf_state_dict(tcfg, synth.synth_clip_state_dict(tcfg, seed=7), device=dev)
-        for p_ in teacher_clip.parameters():
-            p_.requires_grad = False
-        E = tcfg.projection_dim               # a wider teacher is bridged to the student inside the module (c5)
-        teacher = PatchTextAggregation(embed_dim=E, num_heads=E // 64, clip_model=teacher_clip,
-                                       tower_precision=args.tower_precision).to(dev)
-    else:
-        teacher = PatchTextAggregation(embed_dim=cfg.projection_dim, num_heads=cfg.projection_dim // 64,
-                                       clip_model=student).to(dev)
-    # the cross-modal block too from a seeded state (its constructor draws from the process's default RNG): the same frozen
-    # teacher in every run and on every rank
-    teacher.cross_modal_attention.load_state_dict(
-        {k: v.to(dev) for k, v in synth.synth_cross_modal_state_dict(teacher.embed_dim, seed=31).items()})
-    hp = argparse.Namespace(learning_rate=1e-6, warmup_steps=0, total_steps=10 ** 6, train_batch_size=args.batch,
-                            eval_batch_size=args.batch)
-    module = CLIPImageDistillation(hp, student, None, teacher=teacher, freeze_mode="north_star",
-                                   process_group=group, student_precision=args.student_precision).to(dev)
+    module, cfg, tcfg, batch = build_workload(args.workload, args.model, args.teacher_model, args.batch, args.regions,
+                                              args.student_precision, args.tower_precision, dev, group, rank)
+    hp = module.hparams
     trainable = [p for p in module.parameters() if p.requires_grad]
     opt = None if args.no_optimizer else optim.FusedAdamW(trainable, lr=hp.learning_rate, max_grad_norm=0.5)
     sync = ddist.GradSync(trainable, group, timing=True) if world > 1 else None
@@ -309,16 +384,7 @@ def main():
         from dclip_amd import functional
         functional.set_grad_ready_hook(sync.on_grads_ready)
         functional.set_grad_alloc(sync.grad_buffer)       # wgrad GEMMs write straight into the all-reduce buckets
-
     B, T = args.batch, cfg.text.max_position_embeddings
-    batch = {                                                     # resident in HBM before the timed region
-        "pixel_values": synth.synth_pixel_values(B, cfg.vision, seed=rank).to(dev),
-        "input_ids": synth.synth_input_ids(B, cfg.text, seed=100 + rank).to(dev),
-    }
-    if meta:
-        batch["regions"] = synth.synth_regions(B, args.regions, tcfg.vision, seed=2000 + rank).to(dev)
-    else:
-        batch["teacher_image_emb"] = synth.synth_embeddings(B, cfg.projection_dim, seed=1000 + rank).to(dev)
 
     timer = GemmTimer()
     if not args.no_gemm_events:
@@ -402,7 +468,9 @@ def main():
         """n calls of fn bracketed by synchronize (+ barrier) on both sides; MAX over ranks, seconds."""
         torch.cuda.synchronize()
         if world > 1:
+            note("barrier in")
             dist.barrier()
+            note("barrier out")
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         out = None
@@ -518,12 +586,8 @@ def main():
         value = world * B * args.steps / elapsed
         step_flops = step_flops_per_image(cfg, T) * B
         teacher_flops = 0.0
-        if meta:      # + R frozen region forwards + the teacher's own text forward + cross-attention (+ the bridge)
-            E, R = tcfg.projection_dim, args.regions
-            teacher_flops = B * (R * (vision_fwd_flops(tcfg.vision) + 2.0 * tcfg.vision.hidden_size * E)
-                                 + text_fwd_flops(tcfg.text, T) + 2.0 * T * tcfg.text.hidden_size * E
-                                 + 8.0 * E * E * (T + R) + 8.0 * T * R * E
-                                 + (4.0 * E * cfg.projection_dim if E != cfg.projection_dim else 0.0))
+        if meta:
+            teacher_flops = meta_teacher_flops(cfg, tcfg, B, args.regions, T)
         gflops, gms, glaunches = timer.summary() if not args.no_gemm_events else (0.0, 0.0, 0)
         n_ev = n_sampled                          # steps of the timed region that carried GEMM events
         if graphed is not None:                  # the eager per-step figures
@@ -616,6 +680,13 @@ def main():
         if comm is not None:
             line["comm"] = dict(comm, backend=backend, ranks=dist.get_world_size(group),
                                 embedding_all_gather_bytes_per_rank=2 * B * cfg.projection_dim * 4)
+        if world == 1 and not meta and not args.no_extra_legs and args.student_precision == "fp32" \
+                and cfg.name == "ViT-B/32" and B == 256 and not args.no_gemm_events:
+            # the default run also times the bf16 config c3 for a few steps (outside the contract's timed region)
+            try:
+                line["extra_configs"] = {"c3_bf16": extra_config_c3(dev, timer)}
+            except Exception as exc:          # informative only: never fail the bench line on it
+                line["extra_configs"] = {"c3_bf16": {"error": f"{type(exc).__name__}: {exc}"[:300]}}
         if world == 1 and not args.no_cpu_baseline:
             secs = float(os.environ.get("DCLIP_BENCH_CPU_SECONDS", "12"))
             line["cpu_baseline"] = cpu_baseline(secs, "north_star")          # same regime as `value`

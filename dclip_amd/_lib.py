@@ -28,6 +28,7 @@ SIGNATURES = {
     "dclip_layernorm_fwd": (I, [P, P, P, P, P, P, I, I, F, P]),
     "dclip_layernorm_bwd_workspace": (Z, [I, I]),
     "dclip_layernorm_bwd": (I, [P, P, P, P, P, P, P, P, P, I, I, I, P, Z, P]),
+    "dclip_layernorm_bwd_ex": (I, [P, P, P, P, P, P, P, P, P, P, P, I, I, I, P, Z, P]),
     "dclip_attention_fwd": (I, [P, P, P, I, I, I, I, P]),
     "dclip_attention_bwd": (I, [P, P, P, P, P, P, I, I, I, I, P]),
     "dclip_attention_cls_fwd": (I, [P, P, P, I, I, I, P]),
@@ -71,6 +72,10 @@ SIGNATURES = {
     "dclip_gemm_bf16_ex": (I, [P, P, P, P, P, P, I, I, I, I, I, I, I, I, P]),
     "dclip_layernorm_fwd_bf16_stats": (I, [P, P, P, P, P, P, I, I, F, P]),
     "dclip_transpose_to_bf16": (I, [P, I, P, P, I, I, I, I, I, P]),
+    "dclip_attention_fwd_io16": (I, [P, P, P, I, I, I, I, P]),
+    "dclip_attention_bwd_io16": (I, [P, P, P, P, P, I, I, I, I, P]),
+    "dclip_mt_weights_record_bytes": (I, []),
+    "dclip_mt_weights_bf16": (I, [P, I, I, P]),
     "dclip_rowsum_bf16": (I, [P, P, I, I, I, P]),
     "dclip_gemm_bf16_splitk_plan": (I, [I, I, I]),
     "dclip_gemm_bf16_splitk_workspace": (Z, [I, I, I]),

@@ -207,7 +207,7 @@ class HipCLIPModel(nn.Module):
         ptrs = {p.data_ptr() for p in self.parameters() if p.requires_grad}
         n = 0
         for e in c.values():
-            if e[2] in ptrs:
+            if isinstance(e, list) and e[2] in ptrs:
                 e[1] = -1
                 n += 1
         return n

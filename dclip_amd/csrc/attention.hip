@@ -132,6 +132,50 @@ __device__ __forceinline__ void mma_tilecols_x_tile(f32x4 (&acc)[4], const float
   }
 }
 
+// ---- bf16 I/O of the short-sequence kernels (the bf16 TRAINING student, configs c3 / c5): q, k, v, the attention
+// output, its gradient and dq / dk / dv travel as bf16 — half the bytes of kernels that are bound by them — while every
+// product, the softmax and the accumulations stay in fp32 exactly as in the fp32 instances.
+typedef unsigned short u16x4a __attribute__((ext_vector_type(4)));
+typedef unsigned short u16x8a __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f32x4 bf4_to_f32(u16x4a b) {
+  f32x4 v;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) v[e] = __builtin_bit_cast(float, (unsigned int)b[e] << 16);
+  return v;
+}
+__device__ __forceinline__ u16x4a f32_to_bf4(f32x4 v) {
+  u16x4a b;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) b[e] = __builtin_bit_cast(unsigned short, (__bf16)v[e]);   // round to nearest even
+  return b;
+}
+// 16 bytes = 8 consecutive bf16 of a row -> the two fp32 slots 2c, 2c+1 of the swizzled LDS image
+__device__ __forceinline__ void commit8(float* tile, int row, int chunk, u16x8a b, bool zero) {
+  f32x4 lo, hi;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    lo[e] = zero ? 0.f : __builtin_bit_cast(float, (unsigned int)b[e] << 16);
+    hi[e] = zero ? 0.f : __builtin_bit_cast(float, (unsigned int)b[4 + e] << 16);
+  }
+  *reinterpret_cast<f32x4*>(tile + row * HD + (((2 * chunk) ^ (row & 15)) << 2)) = lo;
+  *reinterpret_cast<f32x4*>(tile + row * HD + (((2 * chunk + 1) ^ (row & 15)) << 2)) = hi;
+}
+// a [64 rows][64] bf16 tile by 256 threads: 2 chunks of 8 per thread; requested unconditionally (see tile_fetch)
+__device__ __forceinline__ void tile_fetch16(u16x8a (&v)[2], const unsigned short* __restrict__ g, int nrows, size_t ld) {
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    const int id = threadIdx.x + c * 256;
+    v[c] = *reinterpret_cast<const u16x8a*>(g + (size_t)min(id >> 3, nrows - 1) * ld + (id & 7) * 8);
+  }
+}
+__device__ __forceinline__ void tile_commit16(float* tile, u16x8a (&v)[2], int nrows) {
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    const int id = threadIdx.x + c * 256;
+    commit8(tile, id >> 3, id & 7, v[c], (id >> 3) >= nrows);
+  }
+}
+
 __device__ __forceinline__ void zero4(f32x4 (&a)[4]) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) a[i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -263,7 +307,8 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(AttnArgs a, float* __rest
 //     round trip, no online rescaling: the whole row is there), and O^T comes out with 4 consecutive head
 //     dimensions per lane: 16-byte stores.
 //   * 16-row granularity: a causal wave w touches key tiles 0..w only (77 tokens: 15 of the 25 16x16 tiles).
-template <int KT, bool CAUSAL>
+// IO16: a.q / a.k / a.v and `out` are bf16 (see the bf16 I/O note above); lse stays fp32.
+template <int KT, bool CAUSAL, bool IO16 = false>
 __global__ void __launch_bounds__(KT * 64) attn_fwd_rows_kernel(AttnArgs a, float* __restrict__ out,
                                                                 float* __restrict__ lse) {
   constexpr int R = KT * 16;
@@ -278,7 +323,30 @@ __global__ void __launch_bounds__(KT * 64) attn_fwd_rows_kernel(AttnArgs a, floa
   const int query = 16 * wave + l15;
   // Q never goes through LDS: a lane's B-operand fragments are 16-byte pieces of its own query row
   f32x4 qf[4];
-  {
+  if constexpr (IO16) {
+    const unsigned short* qrow =
+        reinterpret_cast<const unsigned short*>(a.q) + ((size_t)b * S + min(query, S - 1)) * a.ldq + h * HD + 4 * qd;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) qf[g] = bf4_to_f32(*reinterpret_cast<const u16x4a*>(qrow + 16 * g));
+    // K and V: R * 8 chunks of 8 bf16 over KT * 64 threads = 2 per thread and tensor, all four requested together
+    const unsigned short* src16[2] = {reinterpret_cast<const unsigned short*>(a.k) + (size_t)b * S * a.ldkv + h * HD,
+                                      reinterpret_cast<const unsigned short*>(a.v) + (size_t)b * S * a.ldkv + h * HD};
+    u16x8a stg[2][2];
+#pragma unroll
+    for (int w = 0; w < 2; ++w)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const int id = threadIdx.x + c * (KT * 64);
+        stg[w][c] = *reinterpret_cast<const u16x8a*>(src16[w] + (size_t)min(id >> 3, S - 1) * a.ldkv + (id & 7) * 8);
+      }
+#pragma unroll
+    for (int w = 0; w < 2; ++w)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const int id = threadIdx.x + c * (KT * 64);
+        commit8(lds_rows + w * R * HD, id >> 3, id & 7, stg[w][c], (id >> 3) >= S);
+      }
+  } else {
     const float* qrow = a.q + ((size_t)b * S + min(query, S - 1)) * a.ldq + h * HD + 4 * qd;
 #pragma unroll
     for (int g = 0; g < 4; ++g) qf[g] = *reinterpret_cast<const f32x4*>(qrow + 16 * g);   // rows >= S: never stored
@@ -286,7 +354,7 @@ __global__ void __launch_bounds__(KT * 64) attn_fwd_rows_kernel(AttnArgs a, floa
   // K and V of the head: R * 16 chunks over KT * 64 threads = 4 per thread and tensor, all eight loads requested before
   // the first is waited for (rows past the end read row S-1 and are zeroed: see tile_fetch)
   const float* src[2] = {a.k + (size_t)b * S * a.ldkv + h * HD, a.v + (size_t)b * S * a.ldkv + h * HD};
-  {
+  if constexpr (!IO16) {
     f32x4 stg[2][4];
 #pragma unroll
     for (int w = 0; w < 2; ++w)
@@ -358,9 +426,15 @@ __global__ void __launch_bounds__(KT * 64) attn_fwd_rows_kernel(AttnArgs a, floa
     }
   if (query < S) {
     const float inv = 1.0f / sum;
-    float* orow = out + ((size_t)b * S + query) * D + h * HD + 4 * qd;
+    if constexpr (IO16) {
+      unsigned short* orow = reinterpret_cast<unsigned short*>(out) + ((size_t)b * S + query) * D + h * HD + 4 * qd;
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) *reinterpret_cast<f32x4*>(orow + 16 * dt) = o[dt] * inv;
+      for (int dt = 0; dt < 4; ++dt) *reinterpret_cast<u16x4a*>(orow + 16 * dt) = f32_to_bf4(o[dt] * inv);
+    } else {
+      float* orow = out + ((size_t)b * S + query) * D + h * HD + 4 * qd;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) *reinterpret_cast<f32x4*>(orow + 16 * dt) = o[dt] * inv;
+    }
     if (qd == 0) lse[(size_t)bh * S + query] = mx + __logf(sum);
   }
 }
@@ -678,7 +752,8 @@ __global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(AttnArgs a, const flo
 //            an LDS tile for phase B.  dK, dV leave as 16-byte stores.
 //   phase B  the K tile is staged over the (now dead) Q tile; wave w owns QUERIES 16w..16w+15 and forms
 //            dQ^T = K^T dS^T with dS^T read as 16-byte runs of its own rows of the dS tile.
-template <bool CAUSAL>
+// IO16: q / k / v, `out`, `dout` and dq / dk / dv are bf16 (see the bf16 I/O note above); lse fp32.
+template <bool CAUSAL, bool IO16 = false>
 __global__ void __launch_bounds__(256, 3) attn_bwd_lean_kernel(AttnArgs a, const float* __restrict__ out,
                                                                const float* __restrict__ dout, const float* __restrict__ lse,
                                                                float* __restrict__ dq_out, float* __restrict__ dk_out,
@@ -694,6 +769,39 @@ __global__ void __launch_bounds__(256, 3) attn_bwd_lean_kernel(AttnArgs a, const
   const int qd = lane >> 4, l15 = lane & 15;
   const int bh = blockIdx.x, b = bh / H, h = bh % H;
   const int D = H * HD;
+  const int own = 16 * wave + l15, ownc = min(own, S - 1);
+  const float my_lse = lse[(size_t)bh * S + ownc];      // requested with the rest of the prologue's loads
+  f32x4 kf[4], vf[4];
+  float my_dl = 0.f;
+  f32x4 tk[4];                              // phase B's K tile (fp32 instance): kept in registers through phase A
+  u16x8a tk16[2];                           // ... (bf16 instance)
+  if constexpr (IO16) {
+    const unsigned short* qb = reinterpret_cast<const unsigned short*>(a.q) + (size_t)b * S * a.ldq + h * HD;
+    const unsigned short* kb = reinterpret_cast<const unsigned short*>(a.k) + (size_t)b * S * a.ldkv + h * HD;
+    const unsigned short* vb = reinterpret_cast<const unsigned short*>(a.v) + (size_t)b * S * a.ldkv + h * HD;
+    const unsigned short* dob = reinterpret_cast<const unsigned short*>(dout) + (size_t)b * S * D + h * HD;
+    u16x8a tq16[2], tdo16[2];
+    tile_fetch16(tq16, qb, S, (size_t)a.ldq);
+    tile_fetch16(tdo16, dob, S, (size_t)D);
+    tile_fetch16(tk16, kb, S, (size_t)a.ldkv);
+    const unsigned short* krow = kb + (size_t)ownc * a.ldkv + 4 * qd;
+    const unsigned short* vrow = vb + (size_t)ownc * a.ldkv + 4 * qd;
+    const unsigned short* orow = reinterpret_cast<const unsigned short*>(out) + ((size_t)b * S + ownc) * D + h * HD + 4 * qd;
+    const unsigned short* drow = dob + (size_t)ownc * D + 4 * qd;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      kf[g] = bf4_to_f32(*reinterpret_cast<const u16x4a*>(krow + 16 * g));
+      vf[g] = bf4_to_f32(*reinterpret_cast<const u16x4a*>(vrow + 16 * g));
+      const f32x4 o4 = bf4_to_f32(*reinterpret_cast<const u16x4a*>(orow + 16 * g));
+      const f32x4 d4 = bf4_to_f32(*reinterpret_cast<const u16x4a*>(drow + 16 * g));
+      my_dl += (o4[0] * d4[0] + o4[1] * d4[1]) + (o4[2] * d4[2] + o4[3] * d4[3]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    tile_commit16(Qs, tq16, S);
+    tile_commit16(dOs, tdo16, S);
+#pragma unroll
+    for (int c = 0; c < 2; ++c) asm volatile("" ::"v"(tk16[c]));
+  } else {
   const float* qbase = a.q + (size_t)b * S * a.ldq + h * HD;
   const float* kbase = a.k + (size_t)b * S * a.ldkv + h * HD;
   const float* vbase = a.v + (size_t)b * S * a.ldkv + h * HD;
@@ -701,12 +809,8 @@ __global__ void __launch_bounds__(256, 3) attn_bwd_lean_kernel(AttnArgs a, const
   f32x4 tq[4], tdo[4];                      // Q and dO tiles: requested here, written to LDS behind the fragment loads
   tile_fetch(tq, qbase, 0, S, (size_t)a.ldq);
   tile_fetch(tdo, dobase, 0, S, (size_t)D);
-  f32x4 tk[4];                              // phase B's K tile: requested with the rest, kept in registers through phase A
   tile_fetch(tk, kbase, 0, S, (size_t)a.ldkv);
-  const int own = 16 * wave + l15, ownc = min(own, S - 1);
   // own K / V rows as B-operand fragments: row own, head dims 16g + 4qd .. +3
-  f32x4 kf[4], vf[4];
-  float my_dl = 0.f;
   {
     const float* krow = kbase + (size_t)ownc * a.ldkv + 4 * qd;
     const float* vrow = vbase + (size_t)ownc * a.ldkv + 4 * qd;
@@ -721,18 +825,18 @@ __global__ void __launch_bounds__(256, 3) attn_bwd_lean_kernel(AttnArgs a, const
       my_dl += (o4[0] * d4[0] + o4[1] * d4[1]) + (o4[2] * d4[2] + o4[3] * d4[3]);
     }
   }
-  const float my_lse = lse[(size_t)bh * S + ownc];
   __builtin_amdgcn_sched_barrier(0);        // every load of the prologue is in flight before the first wait
   tile_commit(Qs, tq, 0, S);
   tile_commit(dOs, tdo, 0, S);
+#pragma unroll
+  for (int c = 0; c < 4; ++c) asm volatile("" ::"v"(tk[c]));   // (the optimizer would sink these loads to their use in phase B)
+  }
   my_dl += __shfl_xor(my_dl, 16);
   my_dl += __shfl_xor(my_dl, 32);
   if (qd == 0) {
     lse_s[own] = own < S ? my_lse : 0.f;
     dl_s[own] = own < S ? my_dl : 0.f;
   }
-#pragma unroll
-  for (int c = 0; c < 4; ++c) asm volatile("" ::"v"(tk[c]));   // (the optimizer would sink these loads to their use in phase B)
   __syncthreads();
   const int kts = (S + 15) / 16;
   // ---- phase A: own keys, every query tile -> dK, dV, and the dS tile
@@ -780,13 +884,19 @@ __global__ void __launch_bounds__(256, 3) attn_bwd_lean_kernel(AttnArgs a, const
       const size_t o = ((size_t)b * S + own) * ldd + h * HD + 4 * qd;
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
-        *reinterpret_cast<f32x4*>(dk_out + o + 16 * dt) = dk[dt];
-        *reinterpret_cast<f32x4*>(dv_out + o + 16 * dt) = dv[dt];
+        if constexpr (IO16) {
+          *reinterpret_cast<u16x4a*>(reinterpret_cast<unsigned short*>(dk_out) + o + 16 * dt) = f32_to_bf4(dk[dt]);
+          *reinterpret_cast<u16x4a*>(reinterpret_cast<unsigned short*>(dv_out) + o + 16 * dt) = f32_to_bf4(dv[dt]);
+        } else {
+          *reinterpret_cast<f32x4*>(dk_out + o + 16 * dt) = dk[dt];
+          *reinterpret_cast<f32x4*>(dv_out + o + 16 * dt) = dv[dt];
+        }
       }
     }
   }
   __syncthreads();                                   // Q tile dead, dS tile complete
-  tile_commit(Qs, tk, 0, S);                         // K over Q
+  if constexpr (IO16) tile_commit16(Qs, tk16, S);    // K over Q
+  else tile_commit(Qs, tk, 0, S);
   __syncthreads();
   // ---- phase B: own queries -> dQ^T = K^T dS^T
   {
@@ -808,9 +918,15 @@ __global__ void __launch_bounds__(256, 3) attn_bwd_lean_kernel(AttnArgs a, const
         }
       }
     if (own < S) {
-      float* o = dq_out + ((size_t)b * S + own) * ldd + h * HD + 4 * qd;
+      if constexpr (IO16) {
+        unsigned short* o = reinterpret_cast<unsigned short*>(dq_out) + ((size_t)b * S + own) * ldd + h * HD + 4 * qd;
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt) *reinterpret_cast<f32x4*>(o + 16 * dt) = dq[dt];
+        for (int dt = 0; dt < 4; ++dt) *reinterpret_cast<u16x4a*>(o + 16 * dt) = f32_to_bf4(dq[dt]);
+      } else {
+        float* o = dq_out + ((size_t)b * S + own) * ldd + h * HD + 4 * qd;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) *reinterpret_cast<f32x4*>(o + 16 * dt) = dq[dt];
+      }
     }
   }
 }
@@ -1387,6 +1503,59 @@ DCLIP_API int dclip_attention_bwd(const float* qkv, const float* out, const floa
   const int D = H * HD;
   AttnArgs a{qkv, qkv + D, qkv + 2 * D, 3 * D, 3 * D, S, S, H, nullptr};
   return launch_bwd(a, out, dout, lse, dqkv, 3 * D, dqkv + D, dqkv + 2 * D, 3 * D, delta, B, causal, (hipStream_t)stream);
+}
+
+// bf16 I/O forms for the bf16 training student (S <= 80 forward, S <= 64 backward: the 50-token ViT-B/32): qkv16 [B*S][3D],
+// out16 / dout16 [B*S][D], dqkv16 [B*S][3D] are bf16; lse [B*H][S] fp32; arithmetic in fp32 as in the fp32 entry points.
+DCLIP_API int dclip_attention_fwd_io16(const void* qkv16, void* out16, float* lse, int B, int S, int H, int causal, void* stream) {
+  DCLIP_REQUIRE(qkv16 && out16 && lse, "attention_fwd_io16: null pointer");
+  DCLIP_REQUIRE(B > 0 && S > 0 && S <= 80 && H > 0, "attention_fwd_io16: B=%d S=%d (<= 80) H=%d", B, S, H);
+  DCLIP_REQUIRE(((uintptr_t)qkv16 | (uintptr_t)out16) % 16 == 0, "attention_fwd_io16: operands must be 16-byte aligned");
+  const int D = H * HD;
+  const float* q = reinterpret_cast<const float*>(qkv16);          // element pointers are re-typed inside the kernel
+  const unsigned short* q16 = reinterpret_cast<const unsigned short*>(qkv16);
+  AttnArgs a{q, reinterpret_cast<const float*>(q16 + D), reinterpret_cast<const float*>(q16 + 2 * D), 3 * D, 3 * D, S, S, H, nullptr};
+  hipStream_t st = (hipStream_t)stream;
+  float* out = reinterpret_cast<float*>(out16);
+#define FWD16(KT)                                                                                                             \
+  do {                                                                                                                        \
+    const size_t lds = (size_t)2 * KT * 16 * HD * sizeof(float);                                                              \
+    if (causal) hipLaunchKernelGGL((attn_fwd_rows_kernel<KT, true, true>), dim3(B * H), dim3(KT * 64), lds, st, a, out, lse); \
+    else hipLaunchKernelGGL((attn_fwd_rows_kernel<KT, false, true>), dim3(B * H), dim3(KT * 64), lds, st, a, out, lse);       \
+  } while (0)
+  switch (cdiv(S, 16)) {
+    case 1: FWD16(1); break;
+    case 2: FWD16(2); break;
+    case 3: FWD16(3); break;
+    case 4: FWD16(4); break;
+    default: FWD16(5); break;
+  }
+#undef FWD16
+  DCLIP_CHECK_LAUNCH("attention_fwd_io16");
+  return DCLIP_OK;
+}
+
+DCLIP_API int dclip_attention_bwd_io16(const void* qkv16, const void* out16, const void* dout16, const float* lse, void* dqkv16,
+                                       int B, int S, int H, int causal, void* stream) {
+  DCLIP_REQUIRE(qkv16 && out16 && dout16 && lse && dqkv16, "attention_bwd_io16: null pointer");
+  DCLIP_REQUIRE(B > 0 && S > 0 && S <= TS && H > 0, "attention_bwd_io16: B=%d S=%d (<= 64) H=%d", B, S, H);
+  DCLIP_REQUIRE(((uintptr_t)qkv16 | (uintptr_t)out16 | (uintptr_t)dout16 | (uintptr_t)dqkv16) % 16 == 0,
+                "attention_bwd_io16: operands must be 16-byte aligned");
+  const int D = H * HD;
+  const unsigned short* q16 = reinterpret_cast<const unsigned short*>(qkv16);
+  unsigned short* d16 = reinterpret_cast<unsigned short*>(dqkv16);
+  AttnArgs a{reinterpret_cast<const float*>(q16), reinterpret_cast<const float*>(q16 + D), reinterpret_cast<const float*>(q16 + 2 * D),
+             3 * D, 3 * D, S, S, H, nullptr};
+  hipStream_t st = (hipStream_t)stream;
+  const float* o = reinterpret_cast<const float*>(out16);
+  const float* dO = reinterpret_cast<const float*>(dout16);
+  float* dq = reinterpret_cast<float*>(d16);
+  float* dk = reinterpret_cast<float*>(d16 + D);
+  float* dv = reinterpret_cast<float*>(d16 + 2 * D);
+  if (causal) hipLaunchKernelGGL((attn_bwd_lean_kernel<true, true>), dim3(B * H), dim3(256), 0, st, a, o, dO, lse, dq, dk, dv, 3 * D);
+  else hipLaunchKernelGGL((attn_bwd_lean_kernel<false, true>), dim3(B * H), dim3(256), 0, st, a, o, dO, lse, dq, dk, dv, 3 * D);
+  DCLIP_CHECK_LAUNCH("attention_bwd_io16");
+  return DCLIP_OK;
 }
 
 // Last-layer pruning: after the final encoder layer only the CLS row of every image is used (hf:modeling_clip.py:650),

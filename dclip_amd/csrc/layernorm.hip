@@ -59,23 +59,27 @@ __global__ void __launch_bounds__(256) ln_fwd_kernel(const float* __restrict__ x
 }
 
 // Each wave walks rows with a grid stride; per-column dgamma/dbeta partials stay in registers, are summed
-// over the block's 4 waves through LDS and written to partial[blockIdx][2][D].
+// over the block's 4 waves through LDS and written to partial[blockIdx][NS][D].
+// bf16 training path (NS == 3 / dx16): the same pass also leaves what the NEXT two launches of the backward would
+// otherwise re-read dx for — its bf16 copy (the A operand of the following data- and weight-gradient GEMMs: no cast
+// launch) and its column sums (the bias gradient of the Linear whose output gradient dx is: no colsum launch).
 template <int NC, bool EXACT>
 __global__ void __launch_bounds__(256) ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, const float* __restrict__ dres,
                                                      float* __restrict__ dx, float* __restrict__ partial, int rows,
-                                                     int D) {
-  extern __shared__ __attribute__((aligned(16))) float red[];  // [4][2][D]
+                                                     int D, unsigned short* __restrict__ dx16, int NS) {
+  extern __shared__ __attribute__((aligned(16))) float red[];  // [4][NS][D]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int d4 = D >> 2;
-  f32x4 g[NC], dg[NC], db[NC];
+  f32x4 g[NC], dg[NC], db[NC], dsum[NC];
 #pragma unroll
   for (int c = 0; c < NC; ++c) {
     int i = lane + 64 * c;
     g[c] = (EXACT || i < d4) ? reinterpret_cast<const f32x4*>(gamma)[i] : f32x4{0.f, 0.f, 0.f, 0.f};
     dg[c] = f32x4{0.f, 0.f, 0.f, 0.f};
     db[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    dsum[c] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
   const float invD = 1.0f / (float)D;
   const bool has_res = dres != nullptr;                       // wave-uniform
@@ -118,6 +122,14 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const float* __restrict__ d
         f32x4 o = (dyh[c] - c2 - xh[c] * c1) * rs;
         if (has_res) o += rv[c];
         dxr[i] = o;
+        dsum[c] += o;
+        if (dx16) {
+          typedef unsigned short u16x4_t __attribute__((ext_vector_type(4)));
+          u16x4_t b;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) b[e] = __builtin_bit_cast(unsigned short, (__bf16)o[e]);
+          *reinterpret_cast<u16x4_t*>(dx16 + (size_t)row * D + i * 4) = b;
+        }
       }
     }
   }
@@ -126,14 +138,16 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const float* __restrict__ d
     for (int c = 0; c < NC; ++c) {
       int i = lane + 64 * c;
       if (EXACT || i < d4) {
-        reinterpret_cast<f32x4*>(red + (wave * 2 + 0) * D)[i] = dg[c];
-        reinterpret_cast<f32x4*>(red + (wave * 2 + 1) * D)[i] = db[c];
+        reinterpret_cast<f32x4*>(red + (wave * NS + 0) * D)[i] = dg[c];
+        reinterpret_cast<f32x4*>(red + (wave * NS + 1) * D)[i] = db[c];
+        if (NS == 3) reinterpret_cast<f32x4*>(red + (wave * NS + 2) * D)[i] = dsum[c];
       }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < 2 * D; i += 256) {
-      float s = red[i] + red[2 * D + i] + red[4 * D + i] + red[6 * D + i];
-      partial[(size_t)blockIdx.x * 2 * D + i] = s;
+    const int W = NS * D;
+    for (int i = threadIdx.x; i < W; i += 256) {
+      float s = red[i] + red[W + i] + red[2 * W + i] + red[3 * W + i];
+      partial[(size_t)blockIdx.x * W + i] = s;
     }
   }
 }
@@ -144,12 +158,12 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const float* __restrict__ d
 constexpr int RP_COLS = 16, RP_GROUPS = 64;
 __global__ void __launch_bounds__(1024) reduce_partials_kernel(const float* __restrict__ partial, float* __restrict__ out0,
                                                                float* __restrict__ out1, int P, int N0, int N1,
-                                                               int accumulate) {
+                                                               int accumulate, float* __restrict__ out2 = nullptr, int N2 = 0) {
   __shared__ float red[RP_GROUPS][RP_COLS + 1];
   __shared__ float red2[4][RP_COLS];
   const int cl = threadIdx.x % RP_COLS, rg = threadIdx.x / RP_COLS;
   const int n = blockIdx.x * RP_COLS + cl;
-  const int N = N0 + N1;
+  const int N = N0 + N1 + N2;
   float s = 0.f;
   if (n < N)
     for (int p = rg; p < P; p += RP_GROUPS) s += partial[(size_t)p * N + n];
@@ -166,10 +180,10 @@ __global__ void __launch_bounds__(1024) reduce_partials_kernel(const float* __re
   __syncthreads();
   if (threadIdx.x >= RP_COLS || n >= N) return;
   s = (red2[0][cl] + red2[1][cl]) + (red2[2][cl] + red2[3][cl]);
-  float* base = (n < N0) ? out0 : out1;
+  float* base = (n < N0) ? out0 : (n < N0 + N1 ? out1 : out2);
   if (!base) return;
-  float* o = base + ((n < N0) ? n : n - N0);
-  *o = accumulate ? *o + s : s;
+  float* o = base + ((n < N0) ? n : (n < N0 + N1 ? n - N0 : n - N0 - N1));
+  *o = (accumulate && n < N0 + N1) ? *o + s : s;      // (the column sums of dx are always assigned)
 }
 
 // column sums: block = 64 float4-columns x 4 row lanes; grid.y splits the rows
@@ -253,16 +267,25 @@ DCLIP_API int dclip_layernorm_fwd(const float* x, const float* gamma, const floa
 }
 
 DCLIP_API size_t dclip_layernorm_bwd_workspace(int rows, int D) {
-  return (size_t)ln_bwd_blocks(rows) * 2 * D * sizeof(float);
+  return (size_t)ln_bwd_blocks(rows) * 3 * D * sizeof(float);
 }
 
 DCLIP_API int dclip_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean,
                                   const float* rstd, const float* dresidual, float* dx, float* dgamma,
                                   float* dbeta, int rows, int D, int accumulate_param_grads, void* workspace,
                                   size_t workspace_bytes, void* stream) {
+  return dclip_layernorm_bwd_ex(dy, x, gamma, mean, rstd, dresidual, dx, nullptr, dgamma, dbeta, nullptr, rows, D,
+                                accumulate_param_grads, workspace, workspace_bytes, stream);
+}
+
+DCLIP_API int dclip_layernorm_bwd_ex(const float* dy, const float* x, const float* gamma, const float* mean,
+                                     const float* rstd, const float* dresidual, float* dx, void* dx_bf16, float* dgamma,
+                                     float* dbeta, float* dx_colsum, int rows, int D, int accumulate_param_grads,
+                                     void* workspace, size_t workspace_bytes, void* stream) {
   DCLIP_REQUIRE(dy && x && gamma && mean && rstd && dx, "layernorm_bwd: null pointer");
   DCLIP_REQUIRE(rows > 0 && D > 0 && D % 4 == 0 && D <= 256 * MAXC, "layernorm_bwd: bad D=%d", D);
-  const bool want_params = dgamma || dbeta;
+  DCLIP_REQUIRE(!dx_bf16 || (uintptr_t)dx_bf16 % 8 == 0, "layernorm_bwd: dx_bf16 must be 8-byte aligned");
+  const bool want_params = dgamma || dbeta || dx_colsum;
   const int blocks = ln_bwd_blocks(rows);
   if (want_params && (!workspace || workspace_bytes < dclip_layernorm_bwd_workspace(rows, D))) {
     dclip_set_error("layernorm_bwd: workspace too small (%zu < %zu)", workspace_bytes,
@@ -271,10 +294,13 @@ DCLIP_API int dclip_layernorm_bwd(const float* dy, const float* x, const float* 
   }
   float* partial = want_params ? (float*)workspace : nullptr;
   hipStream_t st = (hipStream_t)stream;
-  const size_t lds = want_params ? (size_t)8 * D * sizeof(float) : 0;
+  const int ns = dx_colsum ? 3 : 2;
+  const size_t lds = want_params ? (size_t)4 * ns * D * sizeof(float) : 0;
   const int nc = cdiv(D / 4, 64);
-#define LN_BWD(NC, EX) \
-  hipLaunchKernelGGL((ln_bwd_kernel<NC, EX>), dim3(blocks), dim3(256), lds, st, dy, x, gamma, mean, rstd, dresidual, dx, partial, rows, D)
+  unsigned short* dx16 = (unsigned short*)dx_bf16;
+#define LN_BWD(NC, EX)                                                                                                      \
+  hipLaunchKernelGGL((ln_bwd_kernel<NC, EX>), dim3(blocks), dim3(256), lds, st, dy, x, gamma, mean, rstd, dresidual, dx, partial, \
+                     rows, D, dx16, ns)
   if (D == 512) LN_BWD(2, true);
   else if (D == 768) LN_BWD(3, true);
   else if (D == 1024) LN_BWD(4, true);
@@ -286,8 +312,8 @@ DCLIP_API int dclip_layernorm_bwd(const float* dy, const float* x, const float* 
 #undef LN_BWD
   DCLIP_CHECK_LAUNCH("layernorm_bwd");
   if (want_params) {
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(2 * D, RP_COLS)), dim3(1024), 0, st, partial, dgamma, dbeta, blocks, D,
-                       D, accumulate_param_grads);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(ns * D, RP_COLS)), dim3(1024), 0, st, partial, dgamma, dbeta, blocks, D,
+                       D, accumulate_param_grads, dx_colsum, dx_colsum ? D : 0);
     DCLIP_CHECK_LAUNCH("layernorm_bwd.reduce");
   }
   return DCLIP_OK;

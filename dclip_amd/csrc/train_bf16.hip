@@ -78,6 +78,64 @@ __global__ void __launch_bounds__(256) transpose_to_bf16_kernel(const void* __re
   }
 }
 
+// All GEMM weights of a training tower in ONE launch: every fp32 master W [rows][cols] -> its bf16 copy [rows][ld] (the
+// forward's operand) and its bf16 transpose W^T [cols][ldT] (the data-gradient GEMM's operand), 64x64 tiles, one workgroup
+// per tile, the tensor found from a table of records (as the multi-tensor optimizer does).  The masters change every
+// optimizer step, so this runs once per step: 96 launches (48 casts + 48 transposes for ViT-B) become one.
+struct WeightRef {
+  const float* src;
+  unsigned short* dst;    // may be null
+  unsigned short* dstT;   // may be null
+  int rows, cols, ld, ldT;
+  int tile0, tiles_c;     // first tile index of this tensor; tiles per tile-row
+};
+
+__global__ void __launch_bounds__(256) mt_weights_bf16_kernel(const WeightRef* __restrict__ refs, int ntensors) {
+  __shared__ unsigned short tile[TT * TPAD];
+  int lo = 0, hi = ntensors - 1;                      // last record with tile0 <= blockIdx.x (uniform: scalar code)
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (refs[mid].tile0 <= (int)blockIdx.x) lo = mid;
+    else hi = mid - 1;
+  }
+  const WeightRef t = refs[lo];
+  const int local = blockIdx.x - t.tile0;
+  const int r0 = (local / t.tiles_c) * TT, c0 = (local % t.tiles_c) * TT;
+  const int tid = threadIdx.x;
+  const int lr = tid >> 4, lc = (tid & 15) * 4;
+#pragma unroll
+  for (int pass = 0; pass < 4; ++pass) {
+    const int r = r0 + pass * 16 + lr, c = c0 + lc;
+    u16x4 b = {0, 0, 0, 0};
+    if (r < t.rows) {
+      const float* x = t.src + (size_t)r * t.cols + c;
+      if (c + 3 < t.cols) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x);
+        b = u16x4{bf16_bits(v[0]), bf16_bits(v[1]), bf16_bits(v[2]), bf16_bits(v[3])};
+      } else {
+        for (int e = 0; e < 4; ++e)
+          if (c + e < t.cols) b[e] = bf16_bits(x[e]);
+      }
+      if (t.dst && c < t.ld) *reinterpret_cast<u16x4*>(t.dst + (size_t)r * t.ld + c) = b;   // ld % 4 == 0; zeros past cols
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) tile[(pass * 16 + lr) * TPAD + lc + e] = b[e];
+  }
+  if (!t.dstT) return;                                 // uniform
+  __syncthreads();
+  const int oc = tid >> 3, seg = (tid & 7) * 8;
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    const int c = c0 + pass * 32 + oc, r = r0 + seg;
+    if (c < t.cols && r < t.ldT) {
+      u16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = tile[(seg + e) * TPAD + pass * 32 + oc];
+      *reinterpret_cast<u16x8*>(t.dstT + (size_t)c * t.ldT + r) = o;
+    }
+  }
+}
+
 // one wave per row
 __global__ void __launch_bounds__(256) rowsum_bf16_kernel(const unsigned short* __restrict__ x, float* __restrict__ out, int R,
                                                           int n, int ld) {
@@ -116,6 +174,16 @@ DCLIP_API int dclip_transpose_to_bf16(const void* x, int x_is_bf16, void* yT, vo
     hipLaunchKernelGGL((transpose_to_bf16_kernel<false>), grid, dim3(256), 0, st, x, (unsigned short*)yT,
                        (unsigned short*)y_copy, rows, cols, ldx, ldyT, ldy);
   DCLIP_CHECK_LAUNCH("transpose_to_bf16");
+  return DCLIP_OK;
+}
+
+DCLIP_API int dclip_mt_weights_record_bytes(void) { return (int)sizeof(WeightRef); }
+
+DCLIP_API int dclip_mt_weights_bf16(const void* refs, int ntensors, int total_tiles, void* stream) {
+  DCLIP_REQUIRE(refs && ntensors > 0 && total_tiles > 0, "mt_weights_bf16: bad arguments");
+  hipLaunchKernelGGL(mt_weights_bf16_kernel, dim3(total_tiles), dim3(256), 0, (hipStream_t)stream, (const WeightRef*)refs,
+                     ntensors);
+  DCLIP_CHECK_LAUNCH("mt_weights_bf16");
   return DCLIP_OK;
 }
 

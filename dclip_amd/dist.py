@@ -284,8 +284,19 @@ class GradSync:
         if timed:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        for _b, work in self._work:
-            work.wait()
+        if os.environ.get("DCLIP_SYNC_TRACE"):          # debugging aid: how long the host sat in each bucket's wait()
+            import sys
+            import time
+            t0 = time.perf_counter()
+            waits = []
+            for b, work in self._work:
+                work.wait()
+                waits.append((b, round(time.perf_counter() - t0, 3)))
+            print(f"[GradSync rank {dist.get_rank(self.group)}] finish(): bucket -> seconds since entry {waits}",
+                  file=sys.stderr, flush=True)
+        else:
+            for _b, work in self._work:
+                work.wait()
         if timed:
             e1.record()
             self._wait_events.append((e0, e1))

@@ -369,11 +369,68 @@ def _w16t(cache: dict, key: str, w: torch.Tensor) -> torch.Tensor:
     return e[0]
 
 
+_TRAIN_WEIGHTS = (("qkv", "qkv_w"), ("out", "out_w"), ("fc1", "fc1_w"), ("fc2", "fc2_w"))
+
+
+def refresh_train_weights(cache: dict, layers: List[LayerParams], prefix: str = "v") -> None:
+    """Bring the bf16 copies W and W^T of every encoder-layer GEMM weight of a TRAINING tower up to date before its
+    forward — in ONE launch (ops.mt_weights_bf16) when, as after every optimizer step, all of them are stale: the
+    per-weight path is 48 casts + 48 transposes per step for ViT-B.  The record table lives on the device next to the
+    persistent copies (uploaded once, so the launch is capturable in a HIP graph)."""
+    stale = []
+    for li, lp in enumerate(layers):
+        for short, field in _TRAIN_WEIGHTS:
+            w = getattr(lp, field)
+            for key in (f"{prefix}{li}.{short}", f"{prefix}{li}.{short}.T"):
+                e = cache.get(key)
+                if e is None or e[1] != w._version or e[2] != w.data_ptr():
+                    stale.append((key, w))
+    if not stale:
+        return
+    tables = cache.setdefault("__mt_tables__", {})
+    keys = tuple(k for k, _ in stale)
+    tab = tables.get(keys)
+    if tab is not None and all(cache[k][2] == w.data_ptr() for k, w in stale):
+        ops.mt_weights_bf16(tab["dev"], tab["n"], tab["tiles"])
+        for k, w in stale:
+            cache[k][1] = w._version
+        return
+    # first time this set is stale: the per-weight kernels allocate / refresh the copies ...
+    for key, w in stale:
+        if key.endswith(".T"):
+            _w16t(cache, key[:-2], w)
+        else:
+            _w16(cache, key, w)
+    # ... and a table for exactly this set (all weights after an optimizer step; the trainable subset under a freeze rule)
+    # is built for the following steps — not while a stream is capturing: the upload is a synchronous copy
+    if torch.cuda.is_current_stream_capturing():
+        return
+    recs = {}
+    for key, w in stale:
+        base = key[:-2] if key.endswith(".T") else key
+        r = recs.setdefault(base, [w, None, None])
+        r[2 if key.endswith(".T") else 1] = cache[key][0]
+    dev, n, tiles = ops.mt_weights_table([tuple(r) for r in recs.values()])
+    tables[keys] = {"dev": dev, "n": n, "tiles": tiles}
+
+
+def _attention_io16(M: int, S: int, D: int, I: int) -> bool:
+    """Short sequences on the token-major backward schedule keep q/k/v, the attention output and their gradients in bf16
+    between the GEMMs and the attention kernels (fp32 arithmetic inside, ops.attention_*_io16): the qkv projection writes
+    bf16, no cast launches either side of the attention, half the bytes for kernels that are bound by them."""
+    return S <= 64 and _tokmajor_wgrads(M, D, I) and os.environ.get("DCLIP_BF16_ATTN_IO16", "1") != "0"
+
+
 def layer_fwd_bf16_train(x, p: LayerParams, c: dict, pre: str, B: int, S: int, H: int, causal: bool, eps: float):
     ln1, m1, r1 = ops.layernorm_fwd_bf16(x, p.ln1_w, p.ln1_b, eps, save_stats=True)
-    qkv = ops.gemm_bf16(ln1, _w16(c, pre + "qkv", p.qkv_w), bias=p.qkv_b)            # fp32 out: the attention core is fp32
-    attn, lse = ops.attention_fwd(qkv, B, S, H, causal)
-    attn16 = ops.cast_bf16(attn)
+    if _attention_io16(x.shape[0], S, x.shape[1], p.fc1_w.shape[0]):
+        qkv = ops.gemm_bf16(ln1, _w16(c, pre + "qkv", p.qkv_w), bias=p.qkv_b, out_bf16=True)
+        attn16, lse = ops.attention_fwd_io16(qkv, B, S, H, causal)
+        attn = None
+    else:
+        qkv = ops.gemm_bf16(ln1, _w16(c, pre + "qkv", p.qkv_w), bias=p.qkv_b)        # fp32 out: the attention core is fp32
+        attn, lse = ops.attention_fwd(qkv, B, S, H, causal)
+        attn16 = ops.cast_bf16(attn)
     x1 = ops.gemm_bf16(attn16, _w16(c, pre + "out", p.out_w), bias=p.out_b, residual=x)
     ln2, m2, r2 = ops.layernorm_fwd_bf16(x1, p.ln2_w, p.ln2_b, eps, save_stats=True)
     g16, h16 = ops.gemm_bf16(ln2, _w16(c, pre + "fc1", p.fc1_w), bias=p.fc1_b, gelu=True, out_bf16=True, save_preact=True)
@@ -401,21 +458,27 @@ def _tokmajor_wgrads(M: int, D: int, I: int) -> bool:
 
 
 def layer_bwd_bf16_tokmajor(dx2, p: LayerParams, c: dict, pre: str, saved, B: int, S: int, H: int, causal: bool,
-                            need: Dict[str, bool], alloc=None):
+                            need: Dict[str, bool], alloc=None, dx2_16=None, fc2_b=None, below_fc2_b=None, want_dx16=False):
     """layer_bwd_bf16 with the weight gradients read from the operands as they lie — dW = dY^T X on the token-major form of
-    the ping-pong GEMM (ops.gemm_bf16_wgrad_tokmajor): the fp32 gradients are only CAST to bf16 (the copy the data-gradient
-    GEMM needs anyway), the saved bf16 activations are used as they are, no transposed copies are written."""
+    the ping-pong GEMM (ops.gemm_bf16_wgrad_tokmajor): the saved bf16 activations are used as they are, no transposed
+    copies are written, and the bf16 copies of the fp32 gradients come out of the kernels that PRODUCE those gradients:
+      dx2_16   bf16 copy of the incoming dx2 (LayerNorm1's backward of the layer above wrote it; None: cast here);
+      fc2_b    this layer's fc2 bias gradient = column sums of dx2, already reduced by that same LayerNorm backward;
+      below_fc2_b  where THIS layer's LayerNorm1 backward leaves the column sums of its dx (the layer below's fc2_b);
+      want_dx16    ... and whether it writes the bf16 copy of dx for the layer below.
+    Returns (dx, dx16 or None, grads)."""
     x, m1, r1, ln1, qkv, attn, attn16, lse, x1, m2, r2, ln2, h16, g16 = saved
     D = x.shape[1]
     I = g16.shape[1]
     dev = x.device
     gr: Dict[str, torch.Tensor] = {}
     # ---- fc2
-    dx2_16 = ops.cast_bf16(dx2)
+    if dx2_16 is None:
+        dx2_16 = ops.cast_bf16(dx2)
     if need.get("fc2_w"):
         gr["fc2_w"] = ops.gemm_bf16_wgrad_tokmajor(dx2_16, g16, out=_galloc(alloc, "fc2_w", (D, I), dev))
     if need.get("fc2_b"):
-        gr["fc2_b"] = ops.colsum(dx2, out=_galloc(alloc, "fc2_b", (D,), dev))
+        gr["fc2_b"] = fc2_b if fc2_b is not None else ops.colsum(dx2, out=_galloc(alloc, "fc2_b", (D,), dev))
     dh16 = ops.gemm_bf16(dx2_16, _w16t(c, pre + "fc2", p.fc2_w), k=D, dgelu_of=h16, out_bf16=True)       # [M, I]
     del dx2_16
     # ---- fc1
@@ -425,46 +488,72 @@ def layer_bwd_bf16_tokmajor(dx2, p: LayerParams, c: dict, pre: str, saved, B: in
         gr["fc1_b"] = ops.colsum_bf16(dh16, out=_galloc(alloc, "fc1_b", (I,), dev))
     dln2 = ops.gemm_bf16(dh16, _w16t(c, pre + "fc1", p.fc1_w), k=dh16.shape[1])                          # [M, D] fp32
     del dh16
-    dx1 = _ln_bwd(dln2, x1, p.ln2_w, m2, r2, dx2, bool(need.get("ln2_w") or need.get("ln2_b")), gr, "ln2_w", "ln2_b", alloc)
+    # LayerNorm2 backward: dx1 (+ the skip connection's dx2), its bf16 copy, and out_proj's bias gradient = colsum(dx1)
+    want_ln2 = bool(need.get("ln2_w") or need.get("ln2_b"))
+    out_b = _galloc(alloc, "out_b", (D,), dev) if need.get("out_b") else None
+    dg = _galloc(alloc, "ln2_w", (D,), dev) if want_ln2 else None
+    db = _galloc(alloc, "ln2_b", (D,), dev) if want_ln2 else None
+    dx1, dg, db, dx1_16 = ops.layernorm_bwd(dln2, x1, p.ln2_w, m2, r2, dresidual=dx2, dgamma=dg, dbeta=db,
+                                            need_param_grads=want_ln2, want_bf16=True, dx_colsum=out_b)
+    if want_ln2:
+        gr["ln2_w"], gr["ln2_b"] = dg, db
+    if out_b is not None:
+        gr["out_b"] = out_b
     # ---- out_proj
-    dx1_16 = ops.cast_bf16(dx1)
     if need.get("out_w"):
         gr["out_w"] = ops.gemm_bf16_wgrad_tokmajor(dx1_16, attn16, out=_galloc(alloc, "out_w", (D, D), dev))
-    if need.get("out_b"):
-        gr["out_b"] = ops.colsum(dx1, out=_galloc(alloc, "out_b", (D,), dev))
-    dattn = ops.gemm_bf16(dx1_16, _w16t(c, pre + "out", p.out_w), k=D)                                   # [M, D] fp32
-    del dx1_16
-    dqkv = ops.attention_bwd(qkv, attn, dattn, lse, B, S, H, causal)                                     # fp32 [M, 3D]
+    if qkv.dtype == torch.bfloat16:          # bf16 I/O attention: dO arrives as bf16, dq / dk / dv leave as bf16
+        dattn16 = ops.gemm_bf16(dx1_16, _w16t(c, pre + "out", p.out_w), k=D, out_bf16=True)
+        del dx1_16
+        dqkv16 = ops.attention_bwd_io16(qkv, attn16, dattn16, lse, B, S, H, causal)
+        del dattn16
+        if need.get("qkv_b"):
+            gr["qkv_b"] = ops.colsum_bf16(dqkv16, out=_galloc(alloc, "qkv_b", (3 * D,), dev))
+    else:
+        dattn = ops.gemm_bf16(dx1_16, _w16t(c, pre + "out", p.out_w), k=D)                               # [M, D] fp32
+        del dx1_16
+        dqkv = ops.attention_bwd(qkv, attn, dattn, lse, B, S, H, causal)                                 # fp32 [M, 3D]
+        dqkv16 = ops.cast_bf16(dqkv)
+        if need.get("qkv_b"):
+            gr["qkv_b"] = ops.colsum(dqkv, out=_galloc(alloc, "qkv_b", (3 * D,), dev))
+        del dqkv
     # ---- qkv projection
-    dqkv16 = ops.cast_bf16(dqkv)
     if need.get("qkv_w"):
         gr["qkv_w"] = ops.gemm_bf16_wgrad_tokmajor(dqkv16, ln1, out=_galloc(alloc, "qkv_w", (3 * D, D), dev))
-    if need.get("qkv_b"):
-        gr["qkv_b"] = ops.colsum(dqkv, out=_galloc(alloc, "qkv_b", (3 * D,), dev))
     dln1 = ops.gemm_bf16(dqkv16, _w16t(c, pre + "qkv", p.qkv_w), k=3 * D)
-    del dqkv, dqkv16
-    dx = _ln_bwd(dln1, x, p.ln1_w, m1, r1, dx1, bool(need.get("ln1_w") or need.get("ln1_b")), gr, "ln1_w", "ln1_b", alloc)
-    return dx, gr
+    del dqkv16
+    want_ln1 = bool(need.get("ln1_w") or need.get("ln1_b"))
+    dg = _galloc(alloc, "ln1_w", (D,), dev) if want_ln1 else None
+    db = _galloc(alloc, "ln1_b", (D,), dev) if want_ln1 else None
+    res = ops.layernorm_bwd(dln1, x, p.ln1_w, m1, r1, dresidual=dx1, dgamma=dg, dbeta=db, need_param_grads=want_ln1,
+                            want_bf16=want_dx16, dx_colsum=below_fc2_b)
+    dx, dg, db = res[0], res[1], res[2]
+    if want_ln1:
+        gr["ln1_w"], gr["ln1_b"] = dg, db
+    return dx, (res[3] if want_dx16 else None), gr
 
 
 def layer_bwd_bf16(dx2, p: LayerParams, c: dict, pre: str, saved, B: int, S: int, H: int, causal: bool, need: Dict[str, bool],
-                   alloc=None):
-    """Backward of layer_fwd_bf16_train.  `alloc(field, shape)`: see _galloc — under data parallelism every parameter
-    gradient (split-K weight gradients, bias column sums, LayerNorm dγ/dβ) is written straight into its bucket slice."""
+                   alloc=None, dx2_16=None, fc2_b=None, below_fc2_b=None, want_dx16=False):
+    """Backward of layer_fwd_bf16_train -> (dx, dx16 or None, grads).  `alloc(field, shape)`: see _galloc — under data
+    parallelism every parameter gradient (split-K weight gradients, bias column sums, LayerNorm dγ/dβ) is written straight
+    into its bucket slice.  dx2_16 / fc2_b / below_fc2_b / want_dx16: see layer_bwd_bf16_tokmajor (the transposing
+    schedule below ignores them, except that it fills below_fc2_b so the caller's bookkeeping holds)."""
     x, m1, r1, ln1, qkv, attn, attn16, lse, x1, m2, r2, ln2, h16, g16 = saved
     M = x.shape[0]
     D = x.shape[1]
     I = g16.shape[1]
     dev = x.device
     if _tokmajor_wgrads(M, D, I):
-        return layer_bwd_bf16_tokmajor(dx2, p, c, pre, saved, B, S, H, causal, need, alloc)
+        return layer_bwd_bf16_tokmajor(dx2, p, c, pre, saved, B, S, H, causal, need, alloc, dx2_16, fc2_b, below_fc2_b,
+                                       want_dx16)
     gr: Dict[str, torch.Tensor] = {}
     # ---- fc2
     dx2T, dx2_16 = ops.transpose_bf16(dx2, want_copy=True)
     if need.get("fc2_w"):
         gr["fc2_w"] = ops.gemm_bf16_wgrad(dx2T, ops.transpose_bf16(g16), M, out=_galloc(alloc, "fc2_w", (D, I), dev))
     if need.get("fc2_b"):
-        gr["fc2_b"] = ops.colsum(dx2, out=_galloc(alloc, "fc2_b", (D,), dev))
+        gr["fc2_b"] = fc2_b if fc2_b is not None else ops.colsum(dx2, out=_galloc(alloc, "fc2_b", (D,), dev))
     dh16 = ops.gemm_bf16(dx2_16, _w16t(c, pre + "fc2", p.fc2_w), k=D, dgelu_of=h16, out_bf16=True)       # [M, I]
     del dx2T, dx2_16
     # ---- fc1
@@ -507,6 +596,7 @@ def vision_fwd_bf16_train(p: VisionParams, pixel_values: torch.Tensor, cfg, cach
     emb = ops.vision_assemble_fwd(patch, p.class_embedding, p.pos, B, S, D)
     del patch
     x, m0, r0 = ops.layernorm_fwd(emb, p.pre_w, p.pre_b, v.layer_norm_eps, save_stats=True)
+    refresh_train_weights(cache, p.layers, "v")          # W and W^T of all layers, one launch per optimizer step
     saved_layers = []
     for li, lp in enumerate(p.layers):
         x, sv = layer_fwd_bf16_train(x, lp, cache, f"v{li}.", B, S, H, False, v.layer_norm_eps)
@@ -543,10 +633,19 @@ def vision_bwd_bf16(p: VisionParams, saved, d_out: torch.Tensor, cfg, need: List
     if lowest is None:
         return [grads[n] for n in names]
     dx = ops.scatter_rows(dcls, None, B, S, D)
-    for i in range(len(p.layers) - 1, max(lowest, 0) - 1, -1):
+    dx16, fc2_b = None, None
+    bottom = max(lowest, 0)
+    for i in range(len(p.layers) - 1, bottom - 1, -1):
         lneed = {f: needd[f"layers.{i}.{f}"] for f in LayerParams.FIELDS}
         lalloc = None if alloc is None else (lambda f, shape, i=i: alloc(f"layers.{i}.{f}", shape))
-        dx, gr = layer_bwd_bf16(dx, p.layers[i], cache, f"v{i}.", saved_layers[i], B, S, H, False, lneed, lalloc)
+        # this layer's LayerNorm1 backward also leaves, for the layer below, the bf16 copy of dx and its column sums (= that
+        # layer's fc2 bias gradient, written where `alloc` puts it)
+        below = None
+        if i > bottom and needd[f"layers.{i - 1}.fc2_b"]:
+            below = _galloc(alloc, f"layers.{i - 1}.fc2_b", (D,), dev)
+        dx, dx16, gr = layer_bwd_bf16(dx, p.layers[i], cache, f"v{i}.", saved_layers[i], B, S, H, False, lneed, lalloc,
+                                      dx2_16=dx16, fc2_b=fc2_b, below_fc2_b=below, want_dx16=i > bottom)
+        fc2_b = below
         saved_layers[i] = None
         for f, t in gr.items():
             grads[f"layers.{i}.{f}"] = t

@@ -171,8 +171,10 @@ def layernorm_fwd(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps:
 
 
 def layernorm_bwd(dy, x, gamma, mean, rstd, *, dresidual=None, dgamma=None, dbeta=None, accumulate=False,
-                  need_param_grads=True):
-    """Returns (dx, dgamma, dbeta); dgamma/dbeta are written (or accumulated into) if requested."""
+                  need_param_grads=True, want_bf16: bool = False, dx_colsum: Optional[torch.Tensor] = None):
+    """Returns (dx, dgamma, dbeta); dgamma/dbeta are written (or accumulated into) if requested.
+    bf16 training path: `want_bf16` -> returns (dx, dgamma, dbeta, dx16) with the bf16 copy of dx from the same pass;
+    `dx_colsum` [D] receives the column sums of dx (the bias gradient of the Linear that produced LayerNorm's input)."""
     lib = _lib.load()
     _f32(dy, "dy"), _f32(x, "x"), _f32(gamma, "gamma"), _f32(mean, "mean"), _f32(rstd, "rstd")
     D = x.shape[-1]
@@ -192,12 +194,21 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, *, dresidual=None, dgamma=None, dbet
             raise ValueError("layernorm_bwd: dgamma/dbeta size")
     else:
         dgamma = dbeta = None
-    nbytes = lib.dclip_layernorm_bwd_workspace(rows, D) if need_param_grads else 0
+    if dx_colsum is not None and (_f32(dx_colsum, "dx_colsum").numel() != D):
+        raise ValueError("layernorm_bwd: dx_colsum size")
+    nbytes = lib.dclip_layernorm_bwd_workspace(rows, D) if (need_param_grads or dx_colsum is not None) else 0
     ws = _ws.get(nbytes, x.device)
-    _lib.check(lib.dclip_layernorm_bwd(dy.data_ptr(), x.data_ptr(), gamma.data_ptr(), mean.data_ptr(),
-                                       rstd.data_ptr(), _ptr(dresidual), dx.data_ptr(), _ptr(dgamma), _ptr(dbeta),
-                                       rows, D, int(accumulate), _ptr(ws), nbytes, _stream()), "layernorm_bwd")
-    return dx, dgamma, dbeta
+    if not want_bf16 and dx_colsum is None:
+        _lib.check(lib.dclip_layernorm_bwd(dy.data_ptr(), x.data_ptr(), gamma.data_ptr(), mean.data_ptr(),
+                                           rstd.data_ptr(), _ptr(dresidual), dx.data_ptr(), _ptr(dgamma), _ptr(dbeta),
+                                           rows, D, int(accumulate), _ptr(ws), nbytes, _stream()), "layernorm_bwd")
+        return dx, dgamma, dbeta
+    dx16 = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device) if want_bf16 else None
+    _lib.check(lib.dclip_layernorm_bwd_ex(dy.data_ptr(), x.data_ptr(), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                          _ptr(dresidual), dx.data_ptr(), _ptr(dx16), _ptr(dgamma), _ptr(dbeta),
+                                          _ptr(dx_colsum), rows, D, int(accumulate), _ptr(ws), nbytes, _stream()),
+               "layernorm_bwd_ex")
+    return (dx, dgamma, dbeta, dx16) if want_bf16 else (dx, dgamma, dbeta)
 
 
 # ------------------------------------------------------------------------------------------- attention
@@ -668,6 +679,41 @@ def _out_f32(out: Optional[torch.Tensor], shape, device, name: str) -> torch.Ten
     return out
 
 
+def mt_weights_table(recs):
+    """Device table for mt_weights_bf16 from [(w fp32 [rows, cols...], w16 bf16 [rows, ld] or None, w16T bf16 [cols, ldT] or
+    None)]; returns (table tensor, ntensors, total tiles).  One synchronous upload: build it once, outside graph capture."""
+    import struct
+    lib = _lib.load()
+    assert lib.dclip_mt_weights_record_bytes() == 48
+    blob, t0 = [], 0
+    dev = None
+    for w, w16, w16T in recs:
+        _f32(w, "w")
+        dev = w.device
+        rows = w.shape[0]
+        cols = w.numel() // rows
+        ld = w16.shape[1] if w16 is not None else cols
+        ldT = w16T.shape[1] if w16T is not None else rows
+        if cols % 4 or ld % 4 or ldT % 8:
+            raise ValueError("mt_weights_table: cols / ld must be multiples of 4, ldT of 8")
+        if w16 is not None and (tuple(_bf16(w16, "w16").shape) != (rows, ld)):
+            raise ValueError("mt_weights_table: w16 shape")
+        if w16T is not None and (tuple(_bf16(w16T, "w16T").shape) != (cols, ldT)):
+            raise ValueError("mt_weights_table: w16T shape")
+        tiles_c = (max(cols, ld) + 63) // 64
+        tiles_r = (max(rows, ldT) + 63) // 64
+        blob.append(struct.pack("<QQQiiiiii", w.data_ptr(), _ptr(w16) or 0, _ptr(w16T) or 0, rows, cols, ld, ldT, t0, tiles_c))
+        t0 += tiles_c * tiles_r
+    raw = b"".join(blob)
+    table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)
+    return table, len(recs), t0
+
+
+def mt_weights_bf16(table: torch.Tensor, ntensors: int, total_tiles: int) -> None:
+    lib = _lib.load()
+    _lib.check(lib.dclip_mt_weights_bf16(table.data_ptr(), ntensors, total_tiles, _stream()), "mt_weights_bf16")
+
+
 def rowsum_bf16(x: torch.Tensor, n: Optional[int] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Row sums (fp32) of the first n columns of a bf16 matrix [R, ld]."""
     lib = _lib.load()
@@ -689,6 +735,33 @@ def attention_fwd_bf16(qkv: torch.Tensor, B: int, S: int, H: int, causal: bool) 
     _lib.check(lib.dclip_attention_fwd_bf16(qkv.data_ptr(), out.data_ptr(), B, S, H, int(causal), _stream()),
                "attention_fwd_bf16")
     return out
+
+
+def attention_fwd_io16(qkv: torch.Tensor, B: int, S: int, H: int, causal: bool):
+    """Short sequences (S <= 80), bf16 in / bf16 out, fp32 arithmetic: qkv [B*S, 3*H*64] bf16 -> (context bf16, lse fp32)."""
+    lib = _lib.load()
+    _bf16(qkv, "qkv")
+    if tuple(qkv.shape) != (B * S, 3 * H * 64):
+        raise ValueError(f"attention_fwd_io16: qkv shape {tuple(qkv.shape)} != {(B * S, 3 * H * 64)}")
+    out = torch.empty((B * S, H * 64), dtype=torch.bfloat16, device=qkv.device)
+    lse = torch.empty((B * H, S), dtype=torch.float32, device=qkv.device)
+    _lib.check(lib.dclip_attention_fwd_io16(qkv.data_ptr(), out.data_ptr(), lse.data_ptr(), B, S, H, int(causal), _stream()),
+               "attention_fwd_io16")
+    return out, lse
+
+
+def attention_bwd_io16(qkv, out, dout, lse, B: int, S: int, H: int, causal: bool) -> torch.Tensor:
+    """Backward of attention_fwd_io16 (S <= 64): everything bf16 except lse; returns dqkv [B*S, 3*H*64] bf16."""
+    lib = _lib.load()
+    _bf16(qkv, "qkv"), _bf16(out, "out"), _bf16(dout, "dout"), _f32(lse, "lse")
+    D = H * 64
+    if tuple(qkv.shape) != (B * S, 3 * D) or tuple(out.shape) != (B * S, D) or tuple(dout.shape) != (B * S, D) \
+            or lse.numel() != B * H * S:
+        raise ValueError("attention_bwd_io16: shape mismatch")
+    dqkv = torch.empty_like(qkv)
+    _lib.check(lib.dclip_attention_bwd_io16(qkv.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(), dqkv.data_ptr(),
+                                            B, S, H, int(causal), _stream()), "attention_bwd_io16")
+    return dqkv
 
 
 def gemm_bf16(a: torch.Tensor, w: torch.Tensor, *, n: Optional[int] = None, k: Optional[int] = None,

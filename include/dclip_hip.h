@@ -105,6 +105,16 @@ int dclip_layernorm_bwd(const float* dy, const float* x, const float* gamma, con
                         const float* rstd, const float* dresidual, float* dx, float* dgamma, float* dbeta,
                         int rows, int D, int accumulate_param_grads, void* workspace, size_t workspace_bytes,
                         void* stream);
+/* The bf16 training path's form (configs c3 / c5; nothing in the reference, which is fp32-only —
+ * training/CLIP_image_distill_training.py:40): the same pass also writes, when non-null,
+ *   dx_bf16   [rows][D] bf16 copy of dx — the A operand of the data- and weight-gradient GEMMs that follow;
+ *   dx_colsum [D]       column sums of dx — the bias gradient of the nn.Linear whose output gradient dx is
+ *                       (out_proj.bias for LayerNorm2, the layer below's fc2.bias for LayerNorm1: hf:modeling_clip.py:346-383).
+ * Same workspace as dclip_layernorm_bwd. */
+int dclip_layernorm_bwd_ex(const float* dy, const float* x, const float* gamma, const float* mean,
+                           const float* rstd, const float* dresidual, float* dx, void* dx_bf16, float* dgamma,
+                           float* dbeta, float* dx_colsum, int rows, int D, int accumulate_param_grads,
+                           void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Multi-head self-attention core, head_dim = 64:  O = softmax(Q K^T / 8 [+ causal]) V
@@ -299,6 +309,19 @@ int dclip_layernorm_fwd_bf16_stats(const float* x, const float* gamma, const flo
                                    int rows, int D, float eps, void* stream);
 int dclip_transpose_to_bf16(const void* x, int x_is_bf16, void* yT, void* y_copy, int rows, int cols, int ldx, int ldyT,
                             int ldy, void* stream);
+/* Short-sequence self-attention with bf16 I/O for the bf16 training student (configs c3 / c5; eager_attention_forward,
+ * hf:modeling_clip.py:259-277, arithmetic in fp32 as in dclip_attention_fwd / _bwd): qkv16 [B*S][3*H*64], out16 / dout16
+ * [B*S][H*64] and dqkv16 [B*S][3*H*64] are bf16, lse [B*H][S] fp32.  Forward S <= 80, backward S <= 64. */
+int dclip_attention_fwd_io16(const void* qkv16, void* out16, float* lse, int B, int S, int H, int causal, void* stream);
+int dclip_attention_bwd_io16(const void* qkv16, const void* out16, const void* dout16, const float* lse, void* dqkv16, int B,
+                             int S, int H, int causal, void* stream);
+/* Every GEMM weight of a training tower converted in one launch (bf16 training path; no counterpart in the reference):
+ * `refs` = device array of `ntensors` records {const float* src [rows][cols]; uint16* dst [rows][ld] (or null); uint16* dstT
+ * [cols][ldT] (or null); int rows, cols, ld, ldT, tile0, tiles_c} (dclip_mt_weights_record_bytes() bytes each), 64x64
+ * tiles: tiles_c = ceil(max(cols, ld) / 64), tile rows = ceil(max(rows, ldT) / 64), tile0 = running sum, ascending.
+ * cols, ld % 4 == 0; ldT % 8 == 0; padding (ld > cols, ldT > rows) is written as zeros. */
+int dclip_mt_weights_record_bytes(void);
+int dclip_mt_weights_bf16(const void* refs, int ntensors, int total_tiles, void* stream);
 int dclip_rowsum_bf16(const void* x, float* out, int R, int n, int ld, void* stream);
 /* Split-K bf16 GEMM for the weight gradients (few output tiles, contraction over all tokens): fp32 C [M][ldc], no
  * epilogue; `splits` K-slices per 128x128 tile write fp32 partials into the caller's workspace

@@ -267,3 +267,68 @@ def test_bf16_student_under_graph_replay_follows_the_optimizer():
     assert losses[1] != losses[0] and losses[2] != losses[1]          # the updates are visible through the bf16 copies
     for n in names:
         assert torch.equal(dict(eager.named_parameters())[n], dict(graphed.named_parameters())[n]), n
+
+
+@pytest.mark.parametrize("B,S,H,causal", [(8, 50, 12, False), (3, 64, 2, False), (5, 17, 3, False), (4, 50, 8, True), (2, 1, 1, False)])
+def test_attention_io16_equals_the_fp32_kernels_on_rounded_operands(B, S, H, causal):
+    """The bf16-I/O attention kernels are the fp32 kernels with bf16 loads and stores: on operands that ARE bf16 values
+    they must reproduce the fp32 kernels' results rounded to bf16 (same products, same order)."""
+    from dclip_amd import ops
+    dev = torch.device("cuda:0")
+    D = 64 * H
+    qkv16 = (rnd((B * S, 3 * D), 11) * 1.5).to(torch.bfloat16).to(dev)
+    out16, lse16 = ops.attention_fwd_io16(qkv16, B, S, H, causal)
+    out32, lse32 = ops.attention_fwd(qkv16.float(), B, S, H, causal)
+    assert torch.equal(lse16, lse32)
+    assert torch.equal(out16, out32.to(torch.bfloat16))
+    dout16 = rnd((B * S, D), 12).to(torch.bfloat16).to(dev)
+    dq16 = ops.attention_bwd_io16(qkv16, out16, dout16, lse16, B, S, H, causal)
+    dq32 = ops.attention_bwd(qkv16.float(), out16.float(), dout16.float(), lse16, B, S, H, causal)
+    assert dq16.dtype == torch.bfloat16 and torch.equal(dq16, dq32.to(torch.bfloat16))
+    # and against an fp64 attention of the same rounded operands
+    q, k, v = [t.reshape(B, S, H, 64).permute(0, 2, 1, 3).double().cpu() for t in qkv16.float().split(D, dim=1)]
+    sc = q @ k.transpose(-1, -2) * 0.125
+    if causal:
+        sc = sc.masked_fill(torch.triu(torch.ones(S, S, dtype=torch.bool), 1), float("-inf"))
+    ref = (torch.softmax(sc, -1) @ v).permute(0, 2, 1, 3).reshape(B * S, D)
+    assert float((out16.double().cpu() - ref).abs().max() / ref.abs().max()) < 6e-3           # one bf16 rounding of the output
+
+
+def test_layernorm_bwd_ex_bf16_copy_and_column_sums():
+    from dclip_amd import ops
+    dev = torch.device("cuda:0")
+    rows, D = 12800, 768
+    x, dy, res = rnd((rows, D), 1, 2.0).to(dev), rnd((rows, D), 2).to(dev), rnd((rows, D), 3).to(dev)
+    g, b = (1.0 + 0.1 * rnd((D,), 4)).to(dev), rnd((D,), 5).to(dev)
+    _, mean, rstd = ops.layernorm_fwd(x, g, b, 1e-5)
+    dx0, dg0, db0 = ops.layernorm_bwd(dy, x, g, mean, rstd, dresidual=res)
+    cs = torch.empty(D, dtype=torch.float32, device=dev)
+    dx1, dg1, db1, dx16 = ops.layernorm_bwd(dy, x, g, mean, rstd, dresidual=res, want_bf16=True, dx_colsum=cs)
+    assert torch.equal(dx0, dx1) and torch.equal(dg0, dg1) and torch.equal(db0, db1)
+    assert dx16.dtype == torch.bfloat16 and torch.equal(dx16, dx0.to(torch.bfloat16))
+    want = dx0.double().sum(0)
+    assert float((cs.double() - want).abs().max() / want.abs().max()) < 1e-5
+    # without parameter gradients (a frozen LayerNorm): the column sums alone
+    cs2 = torch.empty_like(cs)
+    dx2, _, _ = ops.layernorm_bwd(dy, x, g, mean, rstd, dresidual=res, need_param_grads=False, dx_colsum=cs2)
+    assert torch.equal(dx2, dx0) and torch.equal(cs2, cs)
+
+
+def test_mt_weights_bf16_equals_the_per_weight_kernels():
+    from dclip_amd import ops
+    dev = torch.device("cuda:0")
+    shapes = [(2304, 768), (768, 768), (3072, 768), (768, 3072), (72, 40), (8, 8)]
+    ws = [rnd(s_, 20 + i).to(dev) for i, s_ in enumerate(shapes)]
+    recs = []
+    for w in ws:
+        recs.append((w, torch.zeros_like(ops.cast_bf16(w)), torch.zeros_like(ops.transpose_bf16(w))))
+    table, n, tiles = ops.mt_weights_table(recs)
+    ops.mt_weights_bf16(table, n, tiles)
+    for w, w16, w16T in recs:
+        assert torch.equal(w16, ops.cast_bf16(w)) and torch.equal(w16T, ops.transpose_bf16(w))
+    # a record with only one of the two outputs
+    w = ws[0]
+    only = torch.zeros_like(ops.transpose_bf16(w))
+    table, n, tiles = ops.mt_weights_table([(w, None, only)])
+    ops.mt_weights_bf16(table, n, tiles)
+    assert torch.equal(only, ops.transpose_bf16(w))

@@ -107,7 +107,7 @@ def test_two_rank_trainer_fit_equals_single_process(tmp_path, precision):
             assert worst < 0.02 * LR * steps, worst
         else:
             assert off < 1e-3 and l2 < 0.05 and worst <= 2.01 * LR * steps, (off, l2, worst)
-        assert abs(o["train_loss"] - ref.logged("train_loss")) < 1e-4 * abs(ref.logged("train_loss"))
+        assert abs(o["train_loss"] - ref.logged("train_loss")) < (1e-4 if precision == "fp32" else 2e-3) * abs(ref.logged("train_loss"))
         # hooks only on the boundary micro-batch, every gradient of the hooked tower produced in its bucket slice
         assert o["stats"]["grad_tensors_copied_per_step"] == 0 and o["stats"]["grad_tensors_written_in_place_per_step"] >= 30, o["stats"]
     for n in want:                                                   # the replicas never diverge
@@ -160,6 +160,7 @@ def test_two_rank_teacher_trainer_equals_single_process(tmp_path):
     mp.spawn(_teacher_worker, args=(world, _free_port(), path, out), nprocs=world, join=True)
     dev = torch.device("cuda:0")
     cfg, teacher = _teacher(dev)
+    start = {k: v.detach().cpu().clone() for k, v in teacher.state_dict().items()}
 
     def cat(bs):
         res = []
@@ -177,8 +178,16 @@ def test_two_rank_teacher_trainer_equals_single_process(tmp_path):
     steps = 3 * 2
     for r in range(world):
         worst = max(float((out[r]["sd"][k] - want[k]).abs().max()) for k in want)
-        print(f"teacher trainer rank {r}: max |param - single-process| {worst:.3e}; history {out[r]['hist']} vs {res['history']}")
-        assert worst < 0.02 * 2e-3 * steps, worst
+        # The gradient of the KEY bias of an attention block is zero in exact arithmetic (softmax is shift invariant): what
+        # arrives is rounding noise, which Adam turns into steps of size lr whose signs differ from run to run.  So, as for
+        # the bf16 student above: the deviation is bounded in NUMBER and in ENERGY, the loss history to 1e-4.
+        d_ref = torch.cat([(want[k] - start[k]).reshape(-1) for k in want])
+        d_got = torch.cat([(out[r]["sd"][k] - start[k]).reshape(-1) for k in want])
+        off = float(((d_got - d_ref).abs() > 0.02 * 2e-3 * steps).float().mean())
+        l2 = float((d_got - d_ref).norm() / d_ref.norm())
+        print(f"teacher trainer rank {r}: max |param - single-process| {worst:.3e}, elements off by > 2 % of the update {off:.2e}, "
+              f"relative L2 error of the update {l2:.3e}; history {out[r]['hist']} vs {res['history']}")
+        assert off < 2e-3 and l2 < 0.05 and worst <= 2.01 * 2e-3 * steps, (off, l2, worst)
         for (a, av), (b, bv) in zip(out[r]["hist"], res["history"]):
             assert abs(a - b) < 1e-4 * abs(b) and abs(av - bv) < 1e-4 * abs(bv)
     files = sorted(os.path.basename(f) for f in glob.glob(str(tmp_path / "dp" / "*.pth")))
