@@ -1031,6 +1031,16 @@ DCLIP_API int dclip_gemm_bf16_ex(const void* A, const void* W, void* C, const fl
     DCLIP_CHECK_LAUNCH("gemm_bf16.dma");
     return DCLIP_OK;
   }
+  // A/B aid: DCLIP_BF16_MID_DMA=1 sends what falls below the big-tile threshold (K % 64 == 0) to the 128x128 LDS-DMA kernel,
+  // two workgroups per CU, instead of the register-staged 128x128 one
+  static const bool mid_dma = getenv("DCLIP_BF16_MID_DMA") && atoi(getenv("DCLIP_BF16_MID_DMA")) != 0;
+  if (mid_dma && K % BKH == 0 && (long)cdiv(M, 128) * cdiv(N, 128) >= 256) {
+    GemmBf16Params pb{(const __bf16*)A, (const __bf16*)W, C, bias, residual, M, N, K, lda, ldw, ldc, epilogue, out_bf16, 0, 0,
+                      (unsigned short*)aux, 0, nullptr};
+    launch_dma<128, 128, 2, 2>(pb, st);
+    DCLIP_CHECK_LAUNCH("gemm_bf16.dma128");
+    return DCLIP_OK;
+  }
   const bool small = (long)cdiv(M, 128) * cdiv(N, 128) < 256;  // fewer tiles than CUs: use the finer tile
   const int bm = small ? 64 : 128, bn = bm;
   GemmBf16Params p{(const __bf16*)A, (const __bf16*)W, C, bias, residual, M, N, K, lda, ldw, ldc, epilogue, out_bf16,

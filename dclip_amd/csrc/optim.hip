@@ -154,7 +154,8 @@ __global__ void __launch_bounds__(256) mt_adamw_kernel(const TensorRef* __restri
     *reinterpret_cast<f32x4*>(t.v + i) = vv;
   }
   for (size_t i = e4 + threadIdx.x; i < end; i += 256) {
-    const float gg = COUPLED ? t.g[i] * gs + wd * t.p[i] : t.g[i] * gs;
+    const float gsc = t.g[i] * gs;            // the product first, then ONE fma: the same rounding as the vector path above
+    const float gg = COUPLED ? __builtin_fmaf(t.p[i], wd, gsc) : gsc;
     const float mm = t.m[i] * beta1 + gg * (1.0f - beta1);
     const float vv = t.v[i] * beta2 + gg * gg * (1.0f - beta2);
     t.p[i] = t.p[i] * decay - step * mm / (sqrtf(vv) / bc2_sqrt + eps);

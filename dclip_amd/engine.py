@@ -583,7 +583,9 @@ def layer_bwd_bf16(dx2, p: LayerParams, c: dict, pre: str, saved, B: int, S: int
     dln1 = ops.gemm_bf16(dqkv16, _w16t(c, pre + "qkv", p.qkv_w), k=3 * D)
     del dqkv, dqkvT, dqkv16
     dx = _ln_bwd(dln1, x, p.ln1_w, m1, r1, dx1, bool(need.get("ln1_w") or need.get("ln1_b")), gr, "ln1_w", "ln1_b", alloc)
-    return dx, gr
+    if below_fc2_b is not None:
+        ops.colsum(dx, out=below_fc2_b)
+    return dx, None, gr
 
 
 def vision_fwd_bf16_train(p: VisionParams, pixel_values: torch.Tensor, cfg, cache: dict):

@@ -142,3 +142,60 @@ def test_two_ranks_over_rccl_equal_single_process():
         assert float((out[r]["g_proj"] - g_proj).abs().max()) < 2e-5 * float(g_proj.abs().max())
         assert float((out[r]["g_qkv"] - g_qkv).abs().max()) < 2e-5 * float(g_qkv.abs().max())
         assert out[r]["buckets"] >= 2
+
+
+def _rccl_one_rank_worker(rank, port, B, out):
+    import datetime
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, timeout=datetime.timedelta(seconds=120))
+    from dclip_amd import dist as ddist
+    group = dist.group.WORLD
+    dev = torch.device("cuda:0")
+    cfg, mod = _build(dev, group)
+    batch = _batch(cfg, B)
+    trainable = [p for p in mod.parameters() if p.requires_grad]
+    sync = ddist.GradSync(trainable, group, bucket_mb=0.05, timing=True)
+    losses = []
+    for _ in range(2):                                   # twice: the persistent buckets are reused
+        for p in trainable:
+            p.grad = None
+        share = mod.training_step(batch)
+        with sync.hooks():
+            share.backward()                             # all-reduces launched from the autograd thread, async
+        sync.finish()
+        losses.append(float(share.detach()))
+    total = ddist.global_loss_value(mod.last_losses["loss_image"], mod.last_losses["loss_text"],
+                                    mod.last_losses["loss_contrastive"], group)
+    per_bucket = sync.bucket_allreduce_ms(repeats=2)      # (scales the buckets by world**repeats = 1: gradients intact)
+    t = torch.tensor([1.5], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)             # what bench.py's timed() does with the elapsed time
+    dist.barrier()
+    torch.cuda.synchronize()
+    st = sync.stats()
+    out[0] = dict(losses=losses, total=float(total), maxed=float(t), buckets=len(per_bucket), stats=st,
+                  g_proj=mod.student.visual_projection.weight.grad.cpu(),
+                  g_qkv=mod.student.vision_model.encoder.layers[0].self_attn.qkv_proj.weight.grad.cpu())
+    dist.destroy_process_group()
+
+
+def test_single_rank_rccl_group_runs_the_dp_protocol():
+    """The test box has ONE GPU, so RCCL between ranks cannot run here — but every RCCL ENTRY POINT the N-rank step uses
+    can: a one-rank `nccl` group takes the same calls (all_gather_into_tensor of the embeddings and of the LSE vectors,
+    asynchronous bucket all-reduces launched from inside the backward on the autograd thread, work.wait() on the compute
+    stream, barrier, the float64 MAX all-reduce of bench.py) through RCCL's streams and events.  With one rank every
+    collective is the identity, so loss and gradients must equal the group-less step."""
+    B = 8
+    out = mp.Manager().dict()
+    mp.spawn(_rccl_one_rank_worker, args=(_free_port(), B, out), nprocs=1, join=True)
+    dev = torch.device("cuda:0")
+    cfg, mod = _build(dev, None)
+    loss = mod.training_step(_batch(cfg, B))
+    loss.backward()
+    o = out[0]
+    assert o["losses"][0] == o["losses"][1] and abs(o["losses"][0] - float(loss.detach())) < 1e-6 * abs(float(loss.detach()))
+    assert abs(o["total"] - float(loss.detach())) < 1e-6 * abs(float(loss.detach())) and o["maxed"] == 1.5
+    assert torch.equal(o["g_proj"], mod.student.visual_projection.weight.grad.cpu())
+    assert torch.equal(o["g_qkv"], mod.student.vision_model.encoder.layers[0].self_attn.qkv_proj.weight.grad.cpu())
+    assert o["buckets"] >= 2 and o["stats"]["grad_tensors_copied_per_step"] == 0
+    assert o["stats"]["grad_allreduce_exposed_ms_per_step"] is not None
