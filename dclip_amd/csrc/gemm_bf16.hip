@@ -15,6 +15,7 @@ namespace {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int BKH = 64;  // K-tile in bf16 elements (128 bytes per row)
 
@@ -889,6 +890,303 @@ __global__ void __launch_bounds__(512) gemm_bf16_pp_kernel(GemmBf16Params p) {
 }
 #undef PP_BARRIER
 
+// ---------------------------------------------------------------------------------------------------------------
+// PERSISTENT form of the ping-pong kernel (K-major operands, no split-K): one workgroup per CU walks its share of the
+// tiles, and a tile's epilogue no longer stands between two K loops.  With one 128-KiB workgroup per CU nothing else can
+// run on the CU while it stages C through LDS and stores it (8.6k cycles for a bf16 tile, 36k for fp32 + residual, beside
+// a 43k-cycle K loop at K = 768: profiles/r02_bf16_pingpong_stamps.log), and the next tile's first DMA waits behind it.
+// Here, at the end of a K loop:
+//   1. the NEXT tile's first K-tile is requested by LDS-DMA (the staging buffers are free: nothing of C goes through LDS);
+//   2. the finished tile leaves STRAIGHT FROM THE ACCUMULATORS — a lane holds 4 consecutive columns of 32 (row, column
+//      group) blocks: 16-byte (fp32) or 8-byte (bf16) stores, 4 lanes of a quad row covering 64 / 32 contiguous bytes;
+//      bias, quick-GELU and the bf16 rounding are applied in registers on the way.  Stores are fire-and-forget: the
+//      registers are read at issue, the data drains under the next tile's K loop;
+//   3. the residual is not an epilogue operand any more: the next tile's accumulators are INITIALISED with it (C = R + A W^T
+//      accumulates in the matrix pipe), loaded while the first K-tile is in flight.  vmcnt counts loads and stores together
+//      in issue order, so those loads return only after the previous tile's stores are acknowledged — that wait (and only
+//      for residual tiles) is what remains exposed of the epilogue.
+// Same phases, barriers and counted waits inside the K loop as gemm_bf16_pp_kernel<false>.  Tiles: XCD x (= blockIdx & 7,
+// the hardware's round-robin) owns the same contiguous run of the grouped tile order as in the one-tile-per-workgroup
+// kernels, its 32 workgroups stride through it.
+#define PP_BARRIER()                      \
+  do {                                    \
+    __builtin_amdgcn_sched_barrier(0);    \
+    __builtin_amdgcn_s_barrier();         \
+    __builtin_amdgcn_sched_barrier(0);    \
+  } while (0)
+
+__global__ void __launch_bounds__(512) gemm_bf16_ppp_kernel(GemmBf16Params p) {
+  constexpr int BM = 256, BN = 256, ROW = BKH;
+  constexpr int BUF = (BM + BN) * ROW;
+  __shared__ __attribute__((aligned(16))) unsigned char lds_raw[2 * BUF * 2];   // 128 KiB: the ONLY LDS object
+  __bf16* lds = reinterpret_cast<__bf16*>(lds_raw);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int l15 = lane & 15, quad = lane >> 4;
+  const int nk = p.K / BKH;
+  const int kind = (p.epilogue & DCLIP_EPI_RESIDUAL) ? 3 : (p.epilogue & DCLIP_EPI_GELU) ? 1 : 0;
+  const bool out16 = p.out_bf16 != 0;
+
+  // this workgroup's tiles: ids first, first + stride, ... < last in the grouped order (see xcd_remap16)
+  constexpr int GROUP_M = 8;
+  const int nwg = p.tiles_m * p.tiles_n;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;     // gridDim.x is a multiple of 8
+  const int q8 = nwg >> 3, r8 = nwg & 7;
+  const int xbase = (xcd < r8) ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+  const int xcount = q8 + (xcd < r8 ? 1 : 0);
+  const int per_group = GROUP_M * p.tiles_n;
+
+  const int sw = l15 >> 1;
+  const __bf16* pa0 = lds + (128 * wr + l15) * ROW + (((0 + quad) ^ sw) << 3);
+  const __bf16* pa1 = lds + (128 * wr + l15) * ROW + (((4 + quad) ^ sw) << 3);
+  const __bf16* pb0 = lds + (BM + 64 * wc + l15) * ROW + (((0 + quad) ^ sw) << 3);
+  const __bf16* pb1 = lds + (BM + 64 * wc + l15) * ROW + (((4 + quad) ^ sw) << 3);
+
+  f32x4 acc[8][4];
+  bf16x8 fa[4][2], fb0[2][2], fb1[2][2];
+  // the tile whose results sit in the accumulators (stored at the top of the next iteration)
+  int pm0 = 0, pn0 = 0;
+  bool pending = false;
+
+#define PPP_ISSUE_A(h, buf, kt)                                                                                  \
+  do {                                                                                                           \
+    dma16(a_rsrc, lds + (buf) * BUF + (64 * (h) + 8 * wave) * ROW, a_voff[h][0], (kt) * (BKH * 2));              \
+    dma16(a_rsrc, lds + (buf) * BUF + (128 + 64 * (h) + 8 * wave) * ROW, a_voff[h][1], (kt) * (BKH * 2));        \
+  } while (0)
+#define PPP_ISSUE_B(h, buf, kt)                                                                                  \
+  do {                                                                                                           \
+    dma16(w_rsrc, lds + (buf) * BUF + (BM + 64 * (wave >> 2) + 32 * (h) + 8 * (wave & 3)) * ROW, w_voff[h][0],   \
+          (kt) * (BKH * 2));                                                                                     \
+    dma16(w_rsrc, lds + (buf) * BUF + (BM + 128 + 64 * (wave >> 2) + 32 * (h) + 8 * (wave & 3)) * ROW,           \
+          w_voff[h][1], (kt) * (BKH * 2));                                                                       \
+  } while (0)
+#define PPP_READ_A(qm, off)                                                                         \
+  _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                   \
+    fa[i][0] = *reinterpret_cast<const bf16x8*>(pa0 + (off) + (64 * (qm) + 16 * i) * ROW);          \
+    fa[i][1] = *reinterpret_cast<const bf16x8*>(pa1 + (off) + (64 * (qm) + 16 * i) * ROW);          \
+  }
+#define PPP_READ_B(fb, qn, off)                                                                     \
+  _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                   \
+    fb[j][0] = *reinterpret_cast<const bf16x8*>(pb0 + (off) + (32 * (qn) + 16 * j) * ROW);          \
+    fb[j][1] = *reinterpret_cast<const bf16x8*>(pb1 + (off) + (32 * (qn) + 16 * j) * ROW);          \
+  }
+#define PPP_MFMA(qm, qn, fb)                                                                                        \
+  do {                                                                                                              \
+    __builtin_amdgcn_s_setprio(1);                                                                                  \
+    _Pragma("unroll") for (int s = 0; s < 2; ++s)                                                                   \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                   \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                   \
+      acc[4 * (qm) + i][2 * (qn) + j] =                                                                             \
+          __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j][s], fa[i][s], acc[4 * (qm) + i][2 * (qn) + j], 0, 0, 0);    \
+    __builtin_amdgcn_s_setprio(0);                                                                                  \
+  } while (0)
+
+  // results of tile (pm0, pn0) out of the accumulators: block (i, j) of this wave = rows pm0 + 128 wr + 16 i + l15,
+  // columns pn0 + 64 wc + 16 j + 4 quad .. +3.  Stores go through a buffer descriptor over the tile's rows: a lane whose
+  // row or column group lies outside C gets an out-of-range offset and the hardware drops its write — EVERY wave issues
+  // exactly 32 (64 with a saved pre-activation) store instructions per tile, which the counted waits below rely on.
+  auto store_tile = [&](const f32x4 (&bias4)[4]) {
+    const int rows_left = p.M - pm0;                                   // >= 1
+    const size_t bytes = ((size_t)(min(rows_left, BM) - 1) * p.ldc + p.N) * (out16 ? 2 : 4);
+    const size_t org = (size_t)pm0 * p.ldc;
+    const __amdgpu_buffer_rsrc_t c_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        out16 ? (void*)(reinterpret_cast<unsigned short*>(p.C) + org) : (void*)(reinterpret_cast<float*>(p.C) + org), 0,
+        (int)bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(p.aux ? p.aux + org : reinterpret_cast<unsigned short*>(p.C)), 0,
+        (int)(((size_t)(min(rows_left, BM) - 1) * p.ldc + p.N) * 2), 0x00020000);
+    const int r0 = 128 * wr + l15, cbase = pn0 + 64 * wc + 4 * quad;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int col = cbase + 16 * j;
+        const int el = col < p.N ? (r0 + 16 * i) * p.ldc + col : 0x3fffffff;   // element offset inside the tile's rows
+        f32x4 v = acc[i][j] + bias4[j];
+        if (kind == 1) {
+          if (p.aux) {                                 // save the pre-activation (bf16) and take the GELU of what was saved
+            const u16x4 h = {f32_to_bf16_bits(v[0]), f32_to_bf16_bits(v[1]), f32_to_bf16_bits(v[2]), f32_to_bf16_bits(v[3])};
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, h), x_rsrc, el * 2, 0, 0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = __builtin_bit_cast(float, (unsigned int)h[e] << 16);
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = quick_gelu_f(v[e]);
+        }
+        if (out16) {
+          const u16x4 o = {f32_to_bf16_bits(v[0]), f32_to_bf16_bits(v[1]), f32_to_bf16_bits(v[2]), f32_to_bf16_bits(v[3])};
+          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), c_rsrc, el * 2, 0, 0);
+        } else {
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), c_rsrc, el * 4, 0, 0);
+        }
+      }
+    }
+  };
+
+  for (int t = slot; t < xcount; t += per_xcd) {
+    const int swz = xbase + t;
+    const int first_m = (swz / per_group) * GROUP_M;
+    const int gsize = min(GROUP_M, p.tiles_m - first_m);
+    const int tile_m = first_m + (swz % per_group) % gsize, tile_n = (swz % per_group) / gsize;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const __bf16* a_org = p.A + (size_t)m0 * p.lda;
+    const __bf16* w_org = p.W + (size_t)n0 * p.ldw;
+    const int a_rows = min(BM, p.M - m0), w_rows = min(BN, p.N - n0);
+    const size_t a_bytes = ((size_t)(a_rows - 1) * p.lda + p.K) * 2, w_bytes = ((size_t)(w_rows - 1) * p.ldw + p.K) * 2;
+    const __amdgpu_buffer_rsrc_t a_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a_org), 0, (int)min(a_bytes, (size_t)0x7fffffff), 0x00020000);
+    const __amdgpu_buffer_rsrc_t w_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(w_org), 0, (int)min(w_bytes, (size_t)0x7fffffff), 0x00020000);
+    int a_voff[2][2], w_voff[2][2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int x = 0; x < 2; ++x) {
+        const int ra = 128 * x + 64 * h + 8 * wave + (lane >> 3), ga = (lane & 7) ^ ((ra >> 1) & 7);
+        a_voff[h][x] = ra < a_rows ? (ra * p.lda + ga * 8) * 2 : 0x7fffffff;   // out of range -> zeros in LDS
+        const int rb = 64 * (2 * x + (wave >> 2)) + 32 * h + 8 * (wave & 3) + (lane >> 3), gb = (lane & 7) ^ ((rb >> 1) & 7);
+        w_voff[h][x] = rb < w_rows ? (rb * p.ldw + gb * 8) * 2 : 0x7fffffff;
+      }
+
+    // ---- tile boundary.  Issue order (vmcnt retires loads and stores in THIS order, so a wait names what may still fly):
+    //   [bias of the finished tile: 4 loads]  [K-tile 0: 8 DMA pieces]  [K-tile 1: 8 pieces, if any]
+    //   [the finished tile's stores: NST = 32 or 64, or 0 on a workgroup's first tile]  [residual tile: 32 loads, kind 3]
+    // The staging buffers are free: everybody is past the previous tile's last LDS read (the K loop's closing barrier).
+    f32x4 bias4[4];
+    if (pending) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int col = pn0 + 64 * wc + 4 * quad + 16 * j;
+        bias4[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (p.epilogue & DCLIP_EPI_BIAS) bias4[j] = *reinterpret_cast<const f32x4*>(p.bias + (col < p.N ? col : 0));
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    PPP_ISSUE_A(0, 0, 0);
+    PPP_ISSUE_B(0, 0, 0);
+    PPP_ISSUE_B(1, 0, 0);
+    PPP_ISSUE_A(1, 0, 0);
+    if (nk > 1) {
+      PPP_ISSUE_B(0, 1, 1);
+      PPP_ISSUE_A(0, 1, 1);
+      PPP_ISSUE_B(1, 1, 1);
+      PPP_ISSUE_A(1, 1, 1);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const int nst = !pending ? 0 : ((kind == 1 && p.aux) ? 64 : 32);          // uniform
+    if (pending) {
+      asm volatile("s_waitcnt vmcnt(16)" ::: "memory");     // the bias (older than the 16 DMA pieces; 8 pieces when nk == 1: it
+      store_tile(bias4);                                      // then waits for some of those too — harmless)
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (kind == 3) {
+      const int rbase = m0 + 128 * wr + l15, cbase = n0 + 64 * wc + 4 * quad;
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)      // unconditional loads from clamped addresses; rows / columns past the end are never stored
+          acc[i][j] = *reinterpret_cast<const f32x4*>(p.residual + (size_t)min(rbase + 16 * i, p.M - 1) * p.ldc +
+                                                      min(cbase + 16 * j, p.N - 4));
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (behind the stores in issue order: their acknowledgements are waited for)
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      // K-tile 0 has landed; K-tile 1's pieces and the stores may still be in flight
+      if (nk == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else if (nst == 0) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else if (nst == 32) asm volatile("s_waitcnt vmcnt(40)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(63)" ::: "memory");                  // 8 + 64 outstanding allowed at most 63: >= 9 retired
+    }
+    PP_BARRIER();
+    if (wr == 1) PP_BARRIER();   // wave row 1 runs one barrier behind wave row 0
+
+    for (int kt = 0; kt < nk; ++kt) {
+      const int cur = kt & 1, off = cur * BUF;
+      const bool n1 = kt + 1 < nk, n2 = kt + 2 < nk;
+      // ---- phase 1
+      PPP_READ_B(fb0, 0, off);
+      __builtin_amdgcn_sched_barrier(0);
+      PPP_READ_A(0, off);
+      __builtin_amdgcn_sched_barrier(0);
+      if (n1 && kt > 0) PPP_ISSUE_A(1, cur ^ 1, kt + 1);   // (K-tile 1's A-half 1 went out at the tile boundary)
+      asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+      PP_BARRIER();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      PPP_MFMA(0, 0, fb0);
+      PP_BARRIER();
+      // ---- phase 2
+      PPP_READ_B(fb1, 1, off);
+      __builtin_amdgcn_sched_barrier(0);
+      if (n2) PPP_ISSUE_B(0, cur, kt + 2);
+      PP_BARRIER();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      PPP_MFMA(0, 1, fb1);
+      PP_BARRIER();
+      // ---- phase 3
+      PPP_READ_A(1, off);
+      __builtin_amdgcn_sched_barrier(0);
+      if (n2) PPP_ISSUE_A(0, cur, kt + 2);
+      PP_BARRIER();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      PPP_MFMA(1, 1, fb1);
+      PP_BARRIER();
+      // ---- phase 4: K-tile kt+1 has landed (this wave's pieces); the three halves of kt+2 just issued stay in flight —
+      // and, in the first iteration of a non-residual tile, the previous tile's stores, which sit between them in issue order
+      if (n2) {
+        PPP_ISSUE_B(1, cur, kt + 2);
+        if (kt > 0 || nst == 0 || kind == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else if (nst == 32) asm volatile("s_waitcnt vmcnt(38)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(63)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      PP_BARRIER();
+      PPP_MFMA(1, 0, fb0);
+      PP_BARRIER();
+    }
+    if (wr == 0) PP_BARRIER();   // balance the stagger: everybody is past its last MFMA phase and LDS read
+    pm0 = m0;
+    pn0 = n0;
+    pending = true;
+  }
+  if (pending) {
+    f32x4 bias4[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int col = pn0 + 64 * wc + 4 * quad + 16 * j;
+      bias4[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (p.epilogue & DCLIP_EPI_BIAS) bias4[j] = *reinterpret_cast<const f32x4*>(p.bias + (col < p.N ? col : 0));
+    }
+    store_tile(bias4);
+  }
+#undef PPP_ISSUE_A
+#undef PPP_ISSUE_B
+#undef PPP_READ_A
+#undef PPP_READ_B
+#undef PPP_MFMA
+}
+#undef PP_BARRIER
+
+// persistent form: K-major operands, whole K, epilogue kinds bias / GELU (+ saved pre-activation) / residual
+// (read per call, not cached: tests and A/B runs switch it inside one process)
+bool persistent_enabled() { return !(getenv("DCLIP_BF16_PERSIST") && atoi(getenv("DCLIP_BF16_PERSIST")) == 0); }
+
+int launch_ppp(GemmBf16Params p, hipStream_t st) {
+  p.tiles_m = cdiv(p.M, 256);
+  p.tiles_n = cdiv(p.N, 256);
+  const int tiles = p.tiles_m * p.tiles_n;
+  int grid = tiles < 256 ? ((tiles + 7) / 8) * 8 : 256;      // a multiple of 8: 32 (or fewer) workgroups per XCD
+  hipLaunchKernelGGL(gemm_bf16_ppp_kernel, dim3(grid), dim3(512), 0, st, p);
+  return DCLIP_OK;
+}
+
 int launch_pp(GemmBf16Params p, hipStream_t st, int splits = 1, bool tok_major = false) {
   p.tiles_m = cdiv(p.M, 256);
   p.tiles_n = cdiv(p.N, 256);
@@ -1022,18 +1320,24 @@ DCLIP_API int dclip_gemm_bf16_ex(const void* A, const void* W, void* C, const fl
   // kernel AND than a 128x128 LDS-DMA variant (two workgroups per CU) on every tower shape, short K included
   // (tools/bf16_gemm_bench.py).  With fp32 outputs and K = 768 it is bound by writing C (944 MB for the qkv
   // projection of 2048 crops): one workgroup per CU cannot overlap that with the next tile's MFMAs.
-  static const int big_min = getenv("DCLIP_BF16_BIG_MIN") ? atoi(getenv("DCLIP_BF16_BIG_MIN")) : 128;   // tuning aid
+  const int big_min = getenv("DCLIP_BF16_BIG_MIN") ? atoi(getenv("DCLIP_BF16_BIG_MIN")) : 128;   // tuning aid (read per call)
   if (K % BKH == 0 && (long)cdiv(M, 256) * cdiv(N, 256) >= big_min) {
     GemmBf16Params pb{(const __bf16*)A, (const __bf16*)W, C, bias, residual, M, N, K, lda, ldw, ldc, epilogue, out_bf16, 0, 0,
                       (unsigned short*)aux, 0, nullptr};
-    if (pingpong_enabled()) launch_pp(pb, st);
+    // persistent form when a CU gets several tiles (the towers' M = 100k shapes: 14 per CU): the epilogue of one tile
+    // overlaps the K loop of the next.  DGELU (an extra side operand in the epilogue) stays on the one-tile kernel.
+    const int persist_min = getenv("DCLIP_BF16_PERSIST_MIN") ? atoi(getenv("DCLIP_BF16_PERSIST_MIN")) : 512;
+    const bool persist = pingpong_enabled() && persistent_enabled() && !(epilogue & DCLIP_EPI_DGELU) && ldc % 4 == 0 &&
+                         (long)cdiv(M, 256) * cdiv(N, 256) >= persist_min;
+    if (persist) launch_ppp(pb, st);
+    else if (pingpong_enabled()) launch_pp(pb, st);
     else launch_dma<256, 256, 2, 4>(pb, st);
     DCLIP_CHECK_LAUNCH("gemm_bf16.dma");
     return DCLIP_OK;
   }
   // A/B aid: DCLIP_BF16_MID_DMA=1 sends what falls below the big-tile threshold (K % 64 == 0) to the 128x128 LDS-DMA kernel,
   // two workgroups per CU, instead of the register-staged 128x128 one
-  static const bool mid_dma = getenv("DCLIP_BF16_MID_DMA") && atoi(getenv("DCLIP_BF16_MID_DMA")) != 0;
+  const bool mid_dma = getenv("DCLIP_BF16_MID_DMA") && atoi(getenv("DCLIP_BF16_MID_DMA")) != 0;
   if (mid_dma && K % BKH == 0 && (long)cdiv(M, 128) * cdiv(N, 128) >= 256) {
     GemmBf16Params pb{(const __bf16*)A, (const __bf16*)W, C, bias, residual, M, N, K, lda, ldw, ldc, epilogue, out_bf16, 0, 0,
                       (unsigned short*)aux, 0, nullptr};

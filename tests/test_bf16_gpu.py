@@ -224,3 +224,37 @@ def test_pingpong_gemm_repeat_launches_are_bit_identical():
     p = subprocess.run([sys.executable, os.path.join(root, "tools", "bf16_gemm_race_screen.py"), "40"], capture_output=True,
                        text=True, timeout=600)
     assert p.returncode == 0 and "RACE SCREEN clean" in p.stdout, p.stdout[-2000:] + p.stderr[-2000:]
+
+
+@pytest.mark.parametrize("M,N,K", [(1000, 520, 64), (2048, 1024, 128), (777, 260, 192), (5000, 768, 768), (256, 256, 64),
+                                   (4096, 2304, 768)])
+def test_persistent_pingpong_gemm_against_the_one_tile_kernel(M, N, K, monkeypatch):
+    """gemm_bf16_ppp_kernel (a workgroup walks several tiles; C leaves straight from the accumulators, the residual is the
+    accumulators' initial value): forced on for small problems here (it normally serves >= 512 tiles), edge tiles in M and
+    N, one / two / many K-tiles, every epilogue it takes.  Against the one-tile ping-pong kernel: bit-identical for bias /
+    GELU / saved pre-activation (same products, same order), fp32-rounding-close for the residual (added first, not last);
+    and against fp64 of the rounded operands."""
+    import os
+    from dclip_amd import ops
+    dev = torch.device("cuda:0")
+    a16, w16 = rnd((M, K), 1).to(torch.bfloat16).to(dev), rnd((N, K), 2, 0.1).to(torch.bfloat16).to(dev)
+    bias, res = rnd((N,), 3).to(dev), rnd((M, N), 4).to(dev)
+    want = a16.double().cpu() @ w16.double().cpu().t() + bias.double().cpu()
+
+    def run():
+        return (ops.gemm_bf16(a16, w16, bias=bias), ops.gemm_bf16(a16, w16), ops.gemm_bf16(a16, w16, bias=bias, out_bf16=True),
+                ops.gemm_bf16(a16, w16, bias=bias, residual=res), ops.gemm_bf16(a16, w16, bias=bias, gelu=True, out_bf16=True),
+                ops.gemm_bf16(a16, w16, bias=bias, gelu=True, out_bf16=True, save_preact=True))
+
+    monkeypatch.setenv("DCLIP_BF16_BIG_MIN", "1")         # both runs below take the 256x256 kernels
+    monkeypatch.setenv("DCLIP_BF16_PERSIST", "0")
+    one = run()
+    monkeypatch.setenv("DCLIP_BF16_PERSIST", "1")
+    monkeypatch.setenv("DCLIP_BF16_PERSIST_MIN", "1")
+    for rep in range(3):                                  # repeated: a race on the counted waits would show as a difference
+        per = run()
+        assert torch.equal(per[0], one[0]) and torch.equal(per[1], one[1]) and torch.equal(per[2], one[2])
+        assert torch.equal(per[4], one[4]) and torch.equal(per[5][0], one[5][0]) and torch.equal(per[5][1], one[5][1])
+        assert float((per[3] - one[3]).abs().max()) <= 2e-6 * float(one[3].abs().max())
+    assert float((per[0].double().cpu() - want).abs().max() / want.abs().max()) < 2e-6 * max(1.0, K ** 0.5)
+    assert float((per[3].double().cpu() - (want + res.double().cpu())).abs().max() / want.abs().max()) < 1e-5

@@ -198,8 +198,9 @@ def test_colsum_bf16():
 
 
 def test_bf16_layer_backward_schedules_agree(monkeypatch):
-    """The token-major weight-gradient schedule (default) and the transposing one (DCLIP_BF16_WGRAD_TN=0) give the same
-    gradients up to fp32 accumulation order."""
+    """The token-major weight-gradient schedule (default; with it q/k/v, the attention output and their gradients travel as
+    bf16) and the transposing one (DCLIP_BF16_WGRAD_TN=0; fp32 attention I/O) give the same gradients up to fp32
+    accumulation order and those extra bf16 roundings."""
     from dclip_amd.clip_model import from_hf_state_dict
     dev = torch.device("cuda:0")
     cfg = dcfg.vit_b32()
@@ -223,7 +224,7 @@ def test_bf16_layer_backward_schedules_agree(monkeypatch):
     for n in grads[0]:
         a, b = grads[0][n], grads[1][n]
         cos = float((a @ b) / (a.norm() * b.norm() + 1e-30))
-        assert cos > 0.999999, (n, cos)
+        assert cos > 0.99995, (n, cos)
 
 
 def test_bf16_student_under_graph_replay_follows_the_optimizer():

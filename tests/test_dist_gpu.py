@@ -167,15 +167,16 @@ def _rccl_one_rank_worker(rank, port, B, out):
         losses.append(float(share.detach()))
     total = ddist.global_loss_value(mod.last_losses["loss_image"], mod.last_losses["loss_text"],
                                     mod.last_losses["loss_contrastive"], group)
-    per_bucket = sync.bucket_allreduce_ms(repeats=2)      # (scales the buckets by world**repeats = 1: gradients intact)
+    g_proj = mod.student.visual_projection.weight.grad.cpu()
+    g_qkv = mod.student.vision_model.encoder.layers[0].self_attn.qkv_proj.weight.grad.cpu()
+    per_bucket = sync.bucket_allreduce_ms(repeats=2)      # (the calibration leg zero-fills the buckets: gradients read before)
     t = torch.tensor([1.5], dtype=torch.float64, device=dev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)             # what bench.py's timed() does with the elapsed time
     dist.barrier()
     torch.cuda.synchronize()
     st = sync.stats()
     out[0] = dict(losses=losses, total=float(total), maxed=float(t), buckets=len(per_bucket), stats=st,
-                  g_proj=mod.student.visual_projection.weight.grad.cpu(),
-                  g_qkv=mod.student.vision_model.encoder.layers[0].self_attn.qkv_proj.weight.grad.cpu())
+                  g_proj=g_proj, g_qkv=g_qkv)
     dist.destroy_process_group()
 
 

@@ -1,0 +1,20 @@
+#!/bin/bash
+# Round 3, fourth GPU call: persistent ping-pong GEMM — parity test, A/B on the tower / student shapes, c3 and c5 lines.
+set -e -o pipefail
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+O=gpurun_out/r03d
+rm -rf $O && mkdir -p $O
+timeout -k 10 900 python3 -m pytest tests/test_bf16_gpu.py tests/test_bf16_train_gpu.py "tests/test_dist_gpu.py::test_single_rank_rccl_group_runs_the_dp_protocol" -q -s -m gpu > $O/tests.log 2>&1 && TRC=0 || TRC=$?
+grep -E "^(FAILED|ERROR)|passed|failed" $O/tests.log | tail -15 || true
+[ $TRC -eq 0 ] || { grep -n "^E " $O/tests.log | head -20; }
+timeout -k 10 300 python3 tools/bf16_persist_ab.py > $O/persist_ab.log 2>&1 || true
+cat $O/persist_ab.log | grep -v amdgpu.ids
+for P in 0 1; do
+  DCLIP_BF16_PERSIST=$P python3 bench.py --workload c3 --student-precision bf16 --tower-precision bf16 --no-cpu-baseline > $O/bench_c3_p$P.json 2> $O/bench_c3_p$P.err
+  python3 -c "import json;d=json.load(open('$O/bench_c3_p$P.json'));print('c3 persist=$P',d['value'],d['ms_per_step'],d['roofline_bf16']['frac'],d['roofline_bf16']['gemm_ms_per_step'],d['config']['loss'])"
+done
+for P in 0 1; do
+  DCLIP_BF16_PERSIST=$P python3 bench.py --workload c5 --batch 512 --steps 4 --warmup 1 --student-precision bf16 --no-cpu-baseline --no-extra-legs > $O/bench_c5_p$P.json 2> $O/bench_c5_p$P.err
+  python3 -c "import json;d=json.load(open('$O/bench_c5_p$P.json'));print('c5 persist=$P',d['value'],d['ms_per_step'],d['roofline_bf16']['frac'],d['roofline_bf16']['gemm_ms_per_step'],d['config']['loss'])"
+done
+echo "tests rc=$TRC"
