@@ -892,22 +892,28 @@ __global__ void __launch_bounds__(512) gemm_bf16_pp_kernel(GemmBf16Params p) {
 
 // ---------------------------------------------------------------------------------------------------------------
 // PERSISTENT form of the ping-pong kernel (K-major operands, no split-K): one workgroup per CU walks its share of the
-// tiles, and a tile's epilogue no longer stands between two K loops.  With one 128-KiB workgroup per CU nothing else can
-// run on the CU while it stages C through LDS and stores it (8.6k cycles for a bf16 tile, 36k for fp32 + residual, beside
-// a 43k-cycle K loop at K = 768: profiles/r02_bf16_pingpong_stamps.log), and the next tile's first DMA waits behind it.
-// Here, at the end of a K loop:
-//   1. the NEXT tile's first K-tile is requested by LDS-DMA (the staging buffers are free: nothing of C goes through LDS);
-//   2. the finished tile leaves STRAIGHT FROM THE ACCUMULATORS — a lane holds 4 consecutive columns of 32 (row, column
-//      group) blocks: 16-byte (fp32) or 8-byte (bf16) stores, 4 lanes of a quad row covering 64 / 32 contiguous bytes;
-//      bias, quick-GELU and the bf16 rounding are applied in registers on the way.  Stores are fire-and-forget: the
-//      registers are read at issue, the data drains under the next tile's K loop;
-//   3. the residual is not an epilogue operand any more: the next tile's accumulators are INITIALISED with it (C = R + A W^T
-//      accumulates in the matrix pipe), loaded while the first K-tile is in flight.  vmcnt counts loads and stores together
-//      in issue order, so those loads return only after the previous tile's stores are acknowledged — that wait (and only
-//      for residual tiles) is what remains exposed of the epilogue.
-// Same phases, barriers and counted waits inside the K loop as gemm_bf16_pp_kernel<false>.  Tiles: XCD x (= blockIdx & 7,
-// the hardware's round-robin) owns the same contiguous run of the grouped tile order as in the one-tile-per-workgroup
-// kernels, its 32 workgroups stride through it.
+// tiles, and the next tile's first K-tiles are in flight while the finished tile is stored.  With one 128-KiB workgroup
+// per CU nothing else runs on the CU between two K loops: the one-tile kernel pays, per tile, the dispatch of a new
+// workgroup, its address set-up and the latency of its first DMA (5-8k cycles before the first MFMA) and an epilogue that
+// takes ALL of the LDS (8.6k cycles for a bf16 tile, 36k for fp32 + residual, beside a 43k-cycle K loop at K = 768:
+// profiles/r02_bf16_pingpong_stamps.log).  Here, at the end of a K loop:
+//   1. the NEXT tile's K-tiles 0 and 1 are requested by LDS-DMA into the two staging buffers (free: everybody is past its
+//      last LDS read) — the epilogue below does not touch them;
+//   2. the finished tile goes out through a SPARE 32-KiB window (the CU has 160 KiB; the staging buffers take 128): 64 rows
+//      (bf16) or 32 rows (fp32) per pass — the wave row that owns them writes its accumulator blocks (bias, quick-GELU and
+//      the bf16 rounding applied in registers), barrier, all 512 threads copy whole 512-byte / 1-KiB rows out with 16-byte
+//      stores, barrier.  The residual (and nothing else) is a side operand of the copy: its loads are requested one pass
+//      ahead — in FRONT of that pass's stores, because vmcnt retires loads and stores in issue order and a load issued
+//      behind stores returns only after they are acknowledged.
+// A first form stored the tile straight from the accumulators (fire-and-forget, the residual as the accumulators' initial
+// value): 8-byte / 16-byte pieces of 16 different rows per store instruction are four times (bf16) / twice (fp32) the
+// write requests of whole rows, and the K loop that was meant to hide them ran slower beside them — measured slower on
+// most shapes, dropped (profiles/r03_bf16_persistent_direct_store_ab.log).
+// Stores go through a buffer descriptor over the tile's rows: a lane whose row or column chunk lies outside C gets an
+// out-of-range offset and the hardware drops its write — every thread issues the SAME number of store instructions per
+// tile, which the counted waits on the DMA pieces rely on.  Same phases, barriers and counted waits inside the K loop as
+// gemm_bf16_pp_kernel<false>.  Tiles: XCD x (= blockIdx & 7, the hardware's round-robin) owns the same contiguous run of
+// the grouped tile order as in the one-tile-per-workgroup kernels, its 32 workgroups stride through it.
 #define PP_BARRIER()                      \
   do {                                    \
     __builtin_amdgcn_sched_barrier(0);    \
@@ -918,8 +924,10 @@ __global__ void __launch_bounds__(512) gemm_bf16_pp_kernel(GemmBf16Params p) {
 __global__ void __launch_bounds__(512) gemm_bf16_ppp_kernel(GemmBf16Params p) {
   constexpr int BM = 256, BN = 256, ROW = BKH;
   constexpr int BUF = (BM + BN) * ROW;
-  __shared__ __attribute__((aligned(16))) unsigned char lds_raw[2 * BUF * 2];   // 128 KiB: the ONLY LDS object
+  constexpr int WIN = 32768;                                                    // the epilogue's window
+  __shared__ __attribute__((aligned(16))) unsigned char lds_raw[2 * BUF * 2 + WIN];   // 128 + 32 KiB: the ONLY LDS object
   __bf16* lds = reinterpret_cast<__bf16*>(lds_raw);
+  unsigned char* win = lds_raw + 2 * BUF * 2;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -983,44 +991,97 @@ __global__ void __launch_bounds__(512) gemm_bf16_ppp_kernel(GemmBf16Params p) {
     __builtin_amdgcn_s_setprio(0);                                                                                  \
   } while (0)
 
-  // results of tile (pm0, pn0) out of the accumulators: block (i, j) of this wave = rows pm0 + 128 wr + 16 i + l15,
-  // columns pn0 + 64 wc + 16 j + 4 quad .. +3.  Stores go through a buffer descriptor over the tile's rows: a lane whose
-  // row or column group lies outside C gets an out-of-range offset and the hardware drops its write — EVERY wave issues
-  // exactly 32 (64 with a saved pre-activation) store instructions per tile, which the counted waits below rely on.
+  // The finished tile (pm0, pn0) out of the accumulators through the window.  Block (i, j) of this wave = rows
+  // 128 wr + 16 i + l15, columns 64 wc + 16 j + 4 quad .. +3 of the tile.
   auto store_tile = [&](const f32x4 (&bias4)[4]) {
     const int rows_left = p.M - pm0;                                   // >= 1
-    const size_t bytes = ((size_t)(min(rows_left, BM) - 1) * p.ldc + p.N) * (out16 ? 2 : 4);
+    const int trows = min(rows_left, BM);
     const size_t org = (size_t)pm0 * p.ldc;
     const __amdgpu_buffer_rsrc_t c_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         out16 ? (void*)(reinterpret_cast<unsigned short*>(p.C) + org) : (void*)(reinterpret_cast<float*>(p.C) + org), 0,
-        (int)bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(p.aux ? p.aux + org : reinterpret_cast<unsigned short*>(p.C)), 0,
-        (int)(((size_t)(min(rows_left, BM) - 1) * p.ldc + p.N) * 2), 0x00020000);
-    const int r0 = 128 * wr + l15, cbase = pn0 + 64 * wc + 4 * quad;
+        (int)(((size_t)(trows - 1) * p.ldc + p.N) * (out16 ? 2 : 4)), 0x00020000);
+    if (out16) {
+      // ---- bf16 C: 4 passes of 64 rows x 512 bytes.  8-byte unit u of row r sits at u ^ (r & 15) (see pp_epilogue_b16).
+      const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+          (void*)(p.aux ? p.aux + org : reinterpret_cast<unsigned short*>(p.C)), 0,
+          (int)(((size_t)(trows - 1) * p.ldc + p.N) * 2), 0x00020000);
+      const bool save = kind == 1 && p.aux;
+      unsigned short* w16 = reinterpret_cast<unsigned short*>(win);
+      const int cg = tid & 31, col = pn0 + 8 * cg;                     // copy: 8 columns = one 16-byte store per thread and row
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+      for (int q = 0; q < 4; ++q) {
+        if (wr == (q >> 1)) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int col = cbase + 16 * j;
-        const int el = col < p.N ? (r0 + 16 * i) * p.ldc + col : 0x3fffffff;   // element offset inside the tile's rows
-        f32x4 v = acc[i][j] + bias4[j];
-        if (kind == 1) {
-          if (p.aux) {                                 // save the pre-activation (bf16) and take the GELU of what was saved
-            const u16x4 h = {f32_to_bf16_bits(v[0]), f32_to_bf16_bits(v[1]), f32_to_bf16_bits(v[2]), f32_to_bf16_bits(v[3])};
-            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, h), x_rsrc, el * 2, 0, 0);
+          for (int ii = 0; ii < 4; ++ii)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = __builtin_bit_cast(float, (unsigned int)h[e] << 16);
-          }
+            for (int j = 0; j < 4; ++j) {
+              f32x4 v = acc[4 * (q & 1) + ii][j] + bias4[j];
+              if (kind == 1 && !save) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = quick_gelu_f(v[e]);
+                for (int e = 0; e < 4; ++e) v[e] = quick_gelu_f(v[e]);
+              }
+              const u16x4 h = {f32_to_bf16_bits(v[0]), f32_to_bf16_bits(v[1]), f32_to_bf16_bits(v[2]), f32_to_bf16_bits(v[3])};
+              const int row = 16 * ii + l15, unit = 16 * wc + 4 * j + quad;
+              *reinterpret_cast<u16x4*>(w16 + row * BN + ((unit ^ (row & 15)) << 2)) = h;
+            }
         }
-        if (out16) {
-          const u16x4 o = {f32_to_bf16_bits(v[0]), f32_to_bf16_bits(v[1]), f32_to_bf16_bits(v[2]), f32_to_bf16_bits(v[3])};
-          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), c_rsrc, el * 2, 0, 0);
-        } else {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        PP_BARRIER();
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+          const int lr = (tid >> 5) + 16 * s4, trow = 64 * q + lr;       // row inside the pass / inside the tile
+          const u16x4 lo = *reinterpret_cast<const u16x4*>(w16 + lr * BN + (((2 * cg) ^ (lr & 15)) << 2));
+          const u16x4 hi = *reinterpret_cast<const u16x4*>(w16 + lr * BN + (((2 * cg + 1) ^ (lr & 15)) << 2));
+          typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+          u16x8 o = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          const int el = col < p.N ? trow * p.ldc + col : 0x3fffffff;   // N % 8 == 0 (host check): a chunk is in or out as a whole
+          if (save) {
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), x_rsrc, el * 2, 0, 0);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = f32_to_bf16_bits(quick_gelu_f(__builtin_bit_cast(float, (unsigned int)o[e] << 16)));
+          }
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), c_rsrc, el * 2, 0, 0);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this pass's LDS reads are done before the next pass overwrites them
+        PP_BARRIER();
+      }
+    } else {
+      // ---- fp32 C (+ residual): 8 passes of 32 rows x 1 KiB.  16-byte granule g of row r sits at g ^ (r & 7) (see pp_epilogue).
+      float* w32 = reinterpret_cast<float*>(win);
+      const int gcol = tid & 63, col = pn0 + 4 * gcol, lr0 = tid >> 6;   // copy: one column group, rows lr0 + 8 k of the pass
+      const bool colok = col < p.N;
+      const int colc = colok ? col : 0;
+      f32x4 side[2][4];                                                 // residual rows of passes q and q + 1
+      auto fetch_side = [&](int q, f32x4 (&dst)[4]) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          dst[k] = *reinterpret_cast<const f32x4*>(p.residual + (size_t)min(pm0 + 32 * q + lr0 + 8 * k, p.M - 1) * p.ldc + colc);
+      };
+      if (kind == 3) fetch_side(0, side[0]);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        if (kind == 3 && q + 1 < 8) fetch_side(q + 1, side[(q + 1) & 1]);
+        if (wr == (q >> 2)) {
+#pragma unroll
+          for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const f32x4 v = acc[2 * (q & 3) + ii][j] + bias4[j];
+              *reinterpret_cast<f32x4*>(w32 + (16 * ii + l15) * BN + (((16 * wc + 4 * j + quad) ^ (l15 & 7)) << 2)) = v;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        PP_BARRIER();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int lr = lr0 + 8 * k, trow = 32 * q + lr;
+          f32x4 v = *reinterpret_cast<const f32x4*>(w32 + lr * BN + ((gcol ^ (lr & 7)) << 2));
+          if (kind == 3) v += side[q & 1][k];
+          const int el = colok ? trow * p.ldc + col : 0x1fffffff;
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), c_rsrc, el * 4, 0, 0);
         }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        PP_BARRIER();
       }
     }
   };
@@ -1052,7 +1113,7 @@ __global__ void __launch_bounds__(512) gemm_bf16_ppp_kernel(GemmBf16Params p) {
 
     // ---- tile boundary.  Issue order (vmcnt retires loads and stores in THIS order, so a wait names what may still fly):
     //   [bias of the finished tile: 4 loads]  [K-tile 0: 8 DMA pieces]  [K-tile 1: 8 pieces, if any]
-    //   [the finished tile's stores: NST = 32 or 64, or 0 on a workgroup's first tile]  [residual tile: 32 loads, kind 3]
+    //   [the finished tile's residual loads and stores, interleaved: NOPS instructions per thread, 0 on a first tile]
     // The staging buffers are free: everybody is past the previous tile's last LDS read (the K loop's closing barrier).
     f32x4 bias4[4];
     if (pending) {
@@ -1075,32 +1136,21 @@ __global__ void __launch_bounds__(512) gemm_bf16_ppp_kernel(GemmBf16Params p) {
       PPP_ISSUE_A(1, 1, 1);
     }
     __builtin_amdgcn_sched_barrier(0);
-    const int nst = !pending ? 0 : ((kind == 1 && p.aux) ? 64 : 32);          // uniform
-    if (pending) {
-      asm volatile("s_waitcnt vmcnt(16)" ::: "memory");     // the bias (older than the 16 DMA pieces; 8 pieces when nk == 1: it
-      store_tile(bias4);                                      // then waits for some of those too — harmless)
-    }
+    // vector-memory instructions one thread issues in store_tile (uniform): bf16 16 stores (+ 16 for a saved pre-activation),
+    // fp32 32 stores (+ 32 residual loads)
+    const int nops = !pending ? 0 : (out16 ? ((kind == 1 && p.aux) ? 32 : 16) : (kind == 3 ? 64 : 32));
+    if (pending) store_tile(bias4);
     __builtin_amdgcn_sched_barrier(0);
-    if (kind == 3) {
-      const int rbase = m0 + 128 * wr + l15, cbase = n0 + 64 * wc + 4 * quad;
 #pragma unroll
-      for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < 8; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)      // unconditional loads from clamped addresses; rows / columns past the end are never stored
-          acc[i][j] = *reinterpret_cast<const f32x4*>(p.residual + (size_t)min(rbase + 16 * i, p.M - 1) * p.ldc +
-                                                      min(cbase + 16 * j, p.N - 4));
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (behind the stores in issue order: their acknowledgements are waited for)
-    } else {
-#pragma unroll
-      for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-      // K-tile 0 has landed; K-tile 1's pieces and the stores may still be in flight
-      if (nk == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      else if (nst == 0) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      else if (nst == 32) asm volatile("s_waitcnt vmcnt(40)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(63)" ::: "memory");                  // 8 + 64 outstanding allowed at most 63: >= 9 retired
-    }
+      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // K-tile 0 has landed; what was issued after it — K-tile 1's 8 pieces and the nops above — may still be in flight
+    if (nk == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (nops == 0) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (nops == 16) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+    else if (nops == 32) asm volatile("s_waitcnt vmcnt(40)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(63)" ::: "memory");                    // 8 + 64 issued after it, 63 allowed: K-tile 0 retired
     PP_BARRIER();
     if (wr == 1) PP_BARRIER();   // wave row 1 runs one barrier behind wave row 0
 
@@ -1138,11 +1188,12 @@ __global__ void __launch_bounds__(512) gemm_bf16_ppp_kernel(GemmBf16Params p) {
       PPP_MFMA(1, 1, fb1);
       PP_BARRIER();
       // ---- phase 4: K-tile kt+1 has landed (this wave's pieces); the three halves of kt+2 just issued stay in flight —
-      // and, in the first iteration of a non-residual tile, the previous tile's stores, which sit between them in issue order
+      // and, in a tile's first iteration, the previous tile's stores, which sit between them in issue order
       if (n2) {
         PPP_ISSUE_B(1, cur, kt + 2);
-        if (kt > 0 || nst == 0 || kind == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else if (nst == 32) asm volatile("s_waitcnt vmcnt(38)" ::: "memory");
+        if (kt > 0 || nops == 0) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else if (nops == 16) asm volatile("s_waitcnt vmcnt(22)" ::: "memory");
+        else if (nops == 32) asm volatile("s_waitcnt vmcnt(38)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(63)" ::: "memory");
       } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1327,7 +1378,7 @@ DCLIP_API int dclip_gemm_bf16_ex(const void* A, const void* W, void* C, const fl
     // persistent form when a CU gets several tiles (the towers' M = 100k shapes: 14 per CU): the epilogue of one tile
     // overlaps the K loop of the next.  DGELU (an extra side operand in the epilogue) stays on the one-tile kernel.
     const int persist_min = getenv("DCLIP_BF16_PERSIST_MIN") ? atoi(getenv("DCLIP_BF16_PERSIST_MIN")) : 512;
-    const bool persist = pingpong_enabled() && persistent_enabled() && !(epilogue & DCLIP_EPI_DGELU) && ldc % 4 == 0 &&
+    const bool persist = pingpong_enabled() && persistent_enabled() && !(epilogue & DCLIP_EPI_DGELU) && ldc % 8 == 0 && N % 8 == 0 &&
                          (long)cdiv(M, 256) * cdiv(N, 256) >= persist_min;
     if (persist) launch_ppp(pb, st);
     else if (pingpong_enabled()) launch_pp(pb, st);
