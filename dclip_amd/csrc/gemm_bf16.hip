@@ -1226,8 +1226,10 @@ __global__ void __launch_bounds__(512) gemm_bf16_ppp_kernel(GemmBf16Params p) {
 #undef PP_BARRIER
 
 // persistent form: K-major operands, whole K, epilogue kinds bias / GELU (+ saved pre-activation) / residual
-// (read per call, not cached: tests and A/B runs switch it inside one process)
-bool persistent_enabled() { return !(getenv("DCLIP_BF16_PERSIST") && atoi(getenv("DCLIP_BF16_PERSIST")) == 0); }
+// OPT-IN (DCLIP_BF16_PERSIST=1): measured slower than the one-tile kernel on 15 of 17 tower / student shapes in both forms
+// (profiles/r03_bf16_persistent_*_ab.log) — kept as an A/B switch with its parity test, not the default.  Read per call, not
+// cached: tests and A/B runs switch it inside one process.
+bool persistent_enabled() { return getenv("DCLIP_BF16_PERSIST") && atoi(getenv("DCLIP_BF16_PERSIST")) != 0; }
 
 int launch_ppp(GemmBf16Params p, hipStream_t st) {
   p.tiles_m = cdiv(p.M, 256);
