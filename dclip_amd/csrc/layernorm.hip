@@ -122,7 +122,7 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const float* __restrict__ d
         f32x4 o = (dyh[c] - c2 - xh[c] * c1) * rs;
         if (has_res) o += rv[c];
         dxr[i] = o;
-        dsum[c] += o;
+        if (NS == 3) dsum[c] += o;
         if (dx16) {
           typedef unsigned short u16x4_t __attribute__((ext_vector_type(4)));
           u16x4_t b;
