@@ -139,7 +139,12 @@ class Trainer:
         self.save_top_k = save_top_k
         self.max_steps = max_steps
         self.saved = []          # (train_loss, path)
-        self.devices = int(devices) if isinstance(devices, int) else len(devices)
+        if isinstance(devices, str):          # Lightning's "auto" / "-1": every GPU of the node; "2": two
+            devices = int(devices) if devices.lstrip("-").isdigit() else -1
+        if isinstance(devices, int):
+            self.devices = devices if devices > 0 else max(1, torch.cuda.device_count())
+        else:
+            self.devices = len(devices)       # a list of device indices
         self.process_group = process_group
         self.dist_backend = dist_backend
         self.bucket_mb = bucket_mb

@@ -14,9 +14,9 @@ KERNELS = {
     "ln_fwd_kernel<3, true>": ("LayerNorm fwd, vision rows (x read, y written, 8 B/elem)", 2 * rows_v * D * F),
     "ln_fwd_kernel<2, true>": ("LayerNorm fwd, text rows", 2 * rows_t * Dt * F),
     "ln_bwd_kernel<3, true>": ("LayerNorm bwd + residual-gradient add (dy, x, dres read; dx written, 16 B/elem)", 4 * rows_v * D * F),
-    "attn_fwd_rows_kernel<4, false>": ("vision attention fwd (q,k,v read once, out written)", 4 * rows_v * D * F),
-    "attn_fwd_rows_kernel<5, true>": ("text causal attention fwd", 4 * rows_t * Dt * F),
-    "attn_bwd_lean_kernel<false>": ("vision attention bwd (q,k,v,o,do read; dq,dk,dv written)", 8 * rows_v * D * F),
+    "attn_fwd_rows_kernel<4, false, false>": ("vision attention fwd (q,k,v read once, out written)", 4 * rows_v * D * F),
+    "attn_fwd_rows_kernel<5, true, false>": ("text causal attention fwd", 4 * rows_t * Dt * F),
+    "attn_bwd_lean_kernel<false, false>": ("vision attention bwd (q,k,v,o,do read; dq,dk,dv written)", 8 * rows_v * D * F),
     "mt_adamw_kernel": ("multi-tensor AdamW (p,g,m,v read; p,m,v written, 28 B/param)", 28 * trainable),
     "mt_sumsq_kernel": ("global grad-norm partial sums (g read)", 4 * trainable),
     "im2col_vec_kernel<false>": ("patch gather (pixels read, columns written)", 2 * B * 3 * 224 * 224 * F),
