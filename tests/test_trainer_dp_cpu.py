@@ -127,8 +127,8 @@ def _worker(rank, world, port, ckpt_dir, out):
     mod = _make_module()
     tr = Trainer(max_epochs=1, gradient_clip_val=None, accumulate_grad_batches=2, checkpoint_dir=ckpt_dir,
                  devices=world, dist_backend="gloo", bucket_mb=0.0001)          # tiny buckets: every tensor its own
-    # 13 per-GPU batches: 6 full rank groups (= 3 optimizer steps at accumulate 2); the 13th is dropped on every rank
-    tr.fit(mod, _batches(13, 4))
+    # 6 full rank groups (= 3 optimizer steps at accumulate 2) + one batch too many, dropped on every rank
+    tr.fit(mod, _batches(6 * world + 1, 4))
     out[rank] = dict(img=mod.img.detach().clone(), tw=mod.txt.weight.detach().clone(), tb=mod.txt.bias.detach().clone(),
                      step=mod.global_step, saved=list(tr.saved), files=sorted(os.listdir(ckpt_dir)),
                      train_loss=mod.logged("train_loss"), launches=dict(launches),
@@ -137,14 +137,17 @@ def _worker(rank, world, port, ckpt_dir, out):
     dist.destroy_process_group()
 
 
-def test_two_rank_fit_equals_single_process_fit_on_concatenated_batches(tmp_path):
+import pytest
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_n_rank_fit_equals_single_process_fit_on_concatenated_batches(tmp_path, world):
     from dclip_amd.lightning_lite import Trainer
-    world = 2
     out = mp.Manager().dict()
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path / "dp"), out), nprocs=world, join=True)
 
-    per_gpu = _batches(13, 4)
-    cat = [{k: torch.cat([per_gpu[2 * j][k], per_gpu[2 * j + 1][k]]) for k in per_gpu[0]} for j in range(6)]
+    per_gpu = _batches(6 * world + 1, 4)
+    cat = [{k: torch.cat([per_gpu[world * j + r][k] for r in range(world)]) for k in per_gpu[0]} for j in range(6)]
     ref = _make_module()
     tr = Trainer(max_epochs=1, gradient_clip_val=None, accumulate_grad_batches=2, checkpoint_dir=str(tmp_path / "one"))
     tr.fit(ref, cat)
@@ -161,8 +164,10 @@ def test_two_rank_fit_equals_single_process_fit_on_concatenated_batches(tmp_path
         # text tower (through .grad) and the gradient-less parameter are launched from finish()
         assert o["launches"]["hooked"] == 3 and o["launches"]["late"] == 3 * 2, o["launches"]
         assert o["unused_grad_is_view"]
-    assert torch.equal(out[0]["img"], out[1]["img"])                      # replicas stay bit-identical
-    assert len(out[0]["saved"]) == 1 and out[1]["saved"] == []            # rank 0 alone writes
+    for r in range(1, world):
+        assert torch.equal(out[0]["img"], out[r]["img"])                  # replicas stay bit-identical
+        assert out[r]["saved"] == []                                      # rank 0 alone writes
+    assert len(out[0]["saved"]) == 1
     assert out[0]["files"] == sorted(os.listdir(tmp_path / "one"))        # same file name (global train_loss)
 
 
