@@ -221,6 +221,12 @@ def meta_teacher_flops(cfg, tcfg, B, R, T) -> float:
                 + (4.0 * E * cfg.projection_dim if E != cfg.projection_dim else 0.0))
 
 
+def bf16_traffic():
+    """HBM-side bytes per bf16 GEMM launch of the c3 step from the committed counter passes (profiles/), or None."""
+    path = os.path.join(REPO, "profiles", "gemm_bf16_traffic.json")
+    return json.load(open(path))["hbm_bytes_per_launch"] if os.path.exists(path) else None
+
+
 def extra_config_c3(dev, timer, steps: int = 5, warmup: int = 2):
     """BASELINE config c3 AS QUOTED (ViT-B/32 student in bf16 + meta-teacher on 8 region crops per image through frozen bf16
     towers, 256 pairs) timed for a few steps AFTER the contract's timed region, so that the driver's record carries the
@@ -261,7 +267,8 @@ def extra_config_c3(dev, timer, steps: int = 5, warmup: int = 2):
            "roofline_bf16": {"bound": "mfma", "kernel": "gemm_bf16_pp_kernel (v_mfma_f32_16x16x32_bf16)",
                              "achieved": round(f16 / (ms16 * 1e-3) / 1e12, 2) if ms16 else None, "peak": 2500.0, "unit": "TFLOP/s",
                              "frac": round(f16 / (ms16 * 1e-3) / 1e12 / 2500.0, 4) if ms16 else None,
-                             "launches_per_step": n16 // steps, "gemm_ms_per_step": round(ms16 / steps, 3)},
+                             "launches_per_step": n16 // steps, "gemm_ms_per_step": round(ms16 / steps, 3),
+                             "traffic": bf16_traffic()},
            "roofline_step": {"bound": "mfma", "unit": "ms", "floor_ms": round(floor_ms, 3), "frac": round(floor_ms / ms, 4),
                              "peak_tflops": 2500.0}}
     del module, opt, batch
@@ -658,7 +665,13 @@ def main():
         g16 = timer.summary(bf16=True) if not args.no_gemm_events else (0.0, 0.0, 0)
         if g16[2] and graphed is None:
             # bf16 GEMM family (frozen teacher towers, bf16 student): its own roofline against the dense bf16 MFMA peak
+            tr16 = None
+            pmc16 = os.path.join(REPO, "profiles", "gemm_bf16_traffic.json")
+            if os.path.exists(pmc16) and args.workload == "c3":        # the committed counter passes are over the c3 step
+                tr16 = json.load(open(pmc16))
             line["roofline_bf16"] = {"bound": "mfma", "kernel": "gemm_bf16_pp_kernel (v_mfma_f32_16x16x32_bf16) / gemm_bf16_kernel (v_mfma_f32_32x32x16_bf16)",
+                                     "traffic": None if tr16 is None else tr16["hbm_bytes_per_launch"],
+                                     "traffic_source": None if tr16 is None else "profiles/gemm_bf16_traffic.json (committed; NOT re-measured in this run)",
                                      "achieved": round(g16[0] / (g16[1] * 1e-3) / 1e12, 2), "peak": 2500.0, "unit": "TFLOP/s",
                                      "frac": round(g16[0] / (g16[1] * 1e-3) / 1e12 / 2500.0, 4),
                                      "launches_per_step": g16[2] // n_ev,
