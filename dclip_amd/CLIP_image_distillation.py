@@ -309,14 +309,27 @@ class CLIPImageDistillation(LightningLikeModule):
         from .data import GpuBatches, MultiModalDataset, identity_collate
         cache = getattr(self.hparams, "train_cache_filename", "train_precache.pkl")
         workers = int(getattr(self.hparams, "num_workers", 0))
-        if getattr(self.hparams, "gpu_preprocess", False):
-            ds = self._dataset(self.hparams.train_file, cache, decode_only=True)
-            loader = DataLoader(ds, batch_size=self.hparams.eval_batch_size, num_workers=workers, shuffle=True,
-                                collate_fn=identity_collate, persistent_workers=workers > 0)
-            return GpuBatches(loader, self.device, self.student.config.vision.image_size)
-        ds = self._dataset(self.hparams.train_file, cache)
-        return DataLoader(ds, batch_size=self.hparams.eval_batch_size, num_workers=workers, pin_memory=True, shuffle=True,
-                          collate_fn=MultiModalDataset.custom_collate_fn)
+        decode_only = bool(getattr(self.hparams, "gpu_preprocess", False))
+        ds = self._dataset(self.hparams.train_file, cache, decode_only=decode_only)
+        # data parallel: every rank LOADS only its share (a DistributedSampler over the items, as Lightning installs one; the
+        # Trainer does not shard such a loader again), so N ranks do not decode the epoch N times
+        sampler = self._rank_sampler(ds, shuffle=True)
+        kw = dict(batch_size=self.hparams.eval_batch_size, num_workers=workers, shuffle=sampler is None, sampler=sampler)
+        if decode_only:
+            loader = DataLoader(ds, collate_fn=identity_collate, persistent_workers=workers > 0, **kw)
+            out = GpuBatches(loader, self.device, self.student.config.vision.image_size)
+        else:
+            out = DataLoader(ds, pin_memory=True, collate_fn=MultiModalDataset.custom_collate_fn, **kw)
+        out.rank_sharded = sampler is not None
+        return out
+
+    def _rank_sampler(self, ds, shuffle: bool):
+        if self.process_group is None:
+            return None
+        import torch.distributed as tdist
+        from torch.utils.data.distributed import DistributedSampler
+        return DistributedSampler(ds, num_replicas=tdist.get_world_size(self.process_group),
+                                  rank=tdist.get_rank(self.process_group), shuffle=shuffle, drop_last=True)
 
     def val_dataloader(self):
         from torch.utils.data import DataLoader
@@ -324,8 +337,11 @@ class CLIPImageDistillation(LightningLikeModule):
         if not getattr(self.hparams, "val_file", None):
             return None
         ds = self._dataset(self.hparams.val_file, getattr(self.hparams, "val_cache_filename", "val_precache.pkl"))
-        return DataLoader(ds, batch_size=self.hparams.eval_batch_size, num_workers=0, pin_memory=False,
-                          collate_fn=MultiModalDataset.custom_collate_fn)
+        sampler = self._rank_sampler(ds, shuffle=False)
+        out = DataLoader(ds, batch_size=self.hparams.eval_batch_size, num_workers=0, pin_memory=False, sampler=sampler,
+                         collate_fn=MultiModalDataset.custom_collate_fn)
+        out.rank_sharded = sampler is not None
+        return out
 
     @staticmethod
     def add_model_specific_args(parent_parser: argparse.ArgumentParser) -> argparse.ArgumentParser:

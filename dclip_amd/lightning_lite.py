@@ -197,7 +197,11 @@ class Trainer:
             elif acc is not None:
                 torch._foreach_zero_(acc)          # nothing of the previous epoch leaks into this epoch's first update
             last = None
-            stream = train if group is None else ddist.shard_batches(train, rank, world)
+            # a loader that already yields only this rank's share (DistributedSampler inside: `rank_sharded`) is taken as it
+            # is; any other stream of per-GPU batches is dealt out round-robin
+            if group is not None and getattr(train, "rank_sharded", False) and hasattr(getattr(train, "sampler", None), "set_epoch"):
+                train.sampler.set_epoch(epoch)
+            stream = train if (group is None or getattr(train, "rank_sharded", False)) else ddist.shard_batches(train, rank, world)
             for i, batch, is_last in _with_last_flag(stream):
                 # Lightning steps on every `accum`-th batch AND on the last batch of the epoch (a trailing partial
                 # group is not dropped); the divisor stays `accum` there as well
@@ -246,7 +250,8 @@ class Trainer:
             if val is not None:
                 model.eval()
                 with torch.no_grad():
-                    for batch in (val if group is None else ddist.shard_batches(val, rank, world)):
+                    for batch in (val if (group is None or getattr(val, "rank_sharded", False))
+                                  else ddist.shard_batches(val, rank, world)):
                         model.validation_step(batch)
             if group is not None and last is not None:
                 # the value Lightning would log on one process: sum of the ranks' shares (one small all-reduce per epoch)

@@ -53,20 +53,30 @@ class JsonPairDataset:
     """`[{image_path, captions|caption, boxes?}]` (json_creation/big_teacher_data.py:86-91) → the reference's batch
     tuples; boxes come from the JSON (or an empty list): there is no detector here."""
 
-    def __init__(self, json_file: str, batch_size: int, shuffle: bool, seed: int = 42):
+    def __init__(self, json_file: str, batch_size: int, shuffle: bool, seed: int = 42, rank: int = 0, world: int = 1):
+        """`rank` / `world`: data parallel — every rank draws the SAME epoch order (same seed) and yields batch i only when
+        i % world == rank; a trailing group that does not cover every rank is dropped (`rank_sharded` tells the trainer not
+        to deal the stream out again)."""
         with open(json_file, "r", encoding="utf-8") as f:
             self.data = json.load(f)
         self.batch_size, self.shuffle = batch_size, shuffle
         self.rng = random.Random(seed)
+        self.rank, self.world = rank, world
+        self.rank_sharded = world > 1
 
     def __len__(self):
-        return (len(self.data) + self.batch_size - 1) // self.batch_size
+        n = (len(self.data) + self.batch_size - 1) // self.batch_size
+        return n if self.world == 1 else n // self.world
 
     def __iter__(self):
         order = list(range(len(self.data)))
         if self.shuffle:
             self.rng.shuffle(order)
-        for i in range(0, len(order), self.batch_size):
+        nb = (len(order) + self.batch_size - 1) // self.batch_size
+        full = nb - nb % self.world                     # batches that belong to complete rank groups
+        for bi, i in enumerate(range(0, len(order), self.batch_size)):
+            if self.world > 1 and (bi >= full or bi % self.world != self.rank):
+                continue
             items = [self.data[j] for j in order[i:i + self.batch_size]]
             caps = []
             for it in items:
@@ -140,9 +150,9 @@ def main(args, teacher: Optional[PatchTextAggregation] = None, train_batches: Op
               f"{sum(p.numel() for p in teacher.parameters()):,}")
 
     if train_batches is None:
-        train_batches = JsonPairDataset(args.train_file, args.batch_size, shuffle=True)
+        train_batches = JsonPairDataset(args.train_file, args.batch_size, shuffle=True, rank=rank, world=world)
     if val_batches is None and getattr(args, "val_file", None) and os.path.exists(args.val_file):
-        val_batches = JsonPairDataset(args.val_file, args.batch_size, shuffle=False)
+        val_batches = JsonPairDataset(args.val_file, args.batch_size, shuffle=False, rank=rank, world=world)
 
     if trainable and trainable[0].is_cuda:
         from .optim import FusedAdam
@@ -152,7 +162,9 @@ def main(args, teacher: Optional[PatchTextAggregation] = None, train_batches: Op
     sync = ddist.GradSync(trainable, group) if group is not None else None      # 8.4 MB: one bucket
 
     def sharded(batches):
-        return batches if group is None else ddist.shard_batches(batches, rank, world)
+        if group is None or getattr(batches, "rank_sharded", False):
+            return batches
+        return ddist.shard_batches(batches, rank, world)
 
     def global_value(share_sum):
         """Sum over ranks of the per-rank loss shares accumulated on the device (one small all-reduce per epoch)."""

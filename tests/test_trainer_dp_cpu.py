@@ -186,3 +186,50 @@ def test_shard_batches_drops_the_incomplete_trailing_group():
     from dclip_amd.dist import shard_batches
     assert list(shard_batches(range(7), 0, 3)) == [0, 3] and list(shard_batches(range(7), 2, 3)) == [2, 5]
     assert list(shard_batches([], 0, 2)) == []
+
+
+def test_json_pair_dataset_rank_shards_cover_the_single_process_order(tmp_path):
+    import json
+    from dclip_amd.train_contrastive_teacher import JsonPairDataset
+    jf = tmp_path / "t.json"
+    jf.write_text(json.dumps([{"image_path": f"i{i}.png", "captions": [f"c{i}"]} for i in range(23)]))
+    one = [b[2] for b in JsonPairDataset(str(jf), 4, True)]
+    shards = [[b[2] for b in JsonPairDataset(str(jf), 4, True, rank=k, world=3)] for k in range(3)]
+    assert [len(s) for s in shards] == [2, 2, 2] and len(JsonPairDataset(str(jf), 4, True, rank=1, world=3)) == 2
+    for j in range(2):                              # group j of the N-rank run = batches 3j .. 3j+2 of the single-process epoch
+        for k in range(3):
+            assert shards[k][j] == one[3 * j + k]
+
+
+def _loader_worker(rank, world, port, jf, cdir, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from dclip_amd import config as dcfg, synth
+    from dclip_amd.clip_model import from_hf_state_dict
+    from dclip_amd.CLIP_image_distillation import CLIPImageDistillation
+    from dclip_amd.patch_text_aggregation import PatchTextAggregation
+    cfg = dcfg.tiny()
+    student = from_hf_state_dict(cfg, synth.synth_clip_state_dict(cfg, seed=7))
+    teacher = PatchTextAggregation(embed_dim=cfg.projection_dim, num_heads=1, clip_model=student)
+    hp = argparse.Namespace(learning_rate=1e-3, warmup_steps=0, total_steps=10, train_batch_size=2, eval_batch_size=2,
+                            train_file=jf, val_file=jf, cache_dir=cdir, train_cache_filename="train_precache.pkl",
+                            val_cache_filename="train_precache.pkl")
+    mod = CLIPImageDistillation(hp, student, None, teacher=teacher, process_group=dist.group.WORLD)
+    tl, vl = mod.train_dataloader(), mod.val_dataloader()
+    out[rank] = dict(sharded=(tl.rank_sharded, vl.rank_sharded), train=[p for b in tl for p in b[2]], val=[p for b in vl for p in b[2]])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_module_loaders_are_rank_sharded_under_a_process_group(tmp_path):
+    """`train_dataloader()` / `val_dataloader()` of a module that has a process group: every rank LOADS only its share of
+    the items (DistributedSampler) and says so, so that `Trainer.fit` does not deal the batches out a second time."""
+    from tests.test_data_cpu import _materialise
+    jf, cdir, _full = _materialise(tmp_path)
+    world = 2
+    out = mp.Manager().dict()
+    mp.spawn(_loader_worker, args=(world, _free_port(), jf, cdir, out), nprocs=world, join=True)
+    assert out[0]["sharded"] == (True, True) and out[1]["sharded"] == (True, True)
+    for split in ("train", "val"):
+        a, b = out[0][split], out[1][split]
+        assert a and b and len(a) == len(b) and not (set(a) & set(b))            # equal shares, nothing loaded twice
