@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdclip_hip.so")
+# DCLIP_LIB_PATH: another BUILD of this library (same-box A/B runs of bench.py, tools/ab/*.so); never a fallback
+LIB_PATH = os.environ.get("DCLIP_LIB_PATH") or os.path.join(_HERE, "libdclip_hip.so")
 
 P = C.c_void_p          # device pointers and the stream
 I = C.c_int
