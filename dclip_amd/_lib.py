@@ -68,6 +68,8 @@ SIGNATURES = {
     "dclip_clip_preprocess_u8": (I, [P, P, P, I, I, I, I, P, P, P, Z, P]),
     "dclip_gemm_bf16": (I, [P, P, P, P, P, I, I, I, I, I, I, I, I, P]),
     "dclip_attention_fwd_bf16": (I, [P, P, I, I, I, I, P]),
+    "dclip_attention_fwd_bf16_lse": (I, [P, P, P, I, I, I, I, P]),
+    "dclip_attention_bwd_bf16": (I, [P, P, P, P, P, I, I, I, I, P]),
     "dclip_cast_f32_bf16": (I, [P, P, I, I, I, I, P]),
     "dclip_layernorm_fwd_bf16": (I, [P, P, P, P, I, I, F, P]),
     "dclip_gemm_bf16_ex": (I, [P, P, P, P, P, P, I, I, I, I, I, I, I, I, P]),

@@ -186,7 +186,8 @@ __global__ void __launch_bounds__(128) attn_fwd_bf16_kernel(const unsigned short
 // after one barrier wave 0 merges the NB + 1 partial results (the flash-attention merge, once per head).
 template <int NB, bool CAUSAL, bool XQ>
 __global__ void __launch_bounds__(64 * NB, (XQ ? 4 : 1)) attn_fwd_bf16_head_kernel(const unsigned short* __restrict__ qkv,
-                                                                     unsigned short* __restrict__ out, int S, int H) {
+                                                                     unsigned short* __restrict__ out, int S, int H,
+                                                                     float* __restrict__ lse = nullptr) {
   constexpr int KB = NB + (XQ ? 1 : 0);            // 32-key blocks staged
   constexpr int CHUNKS = KB * 256, NTHR = 64 * NB, ITER = (CHUNKS + NTHR - 1) / NTHR;
   __shared__ __attribute__((aligned(16))) unsigned char Ks[KB * 32 * 128];
@@ -354,6 +355,8 @@ __global__ void __launch_bounds__(64 * NB, (XQ ? 4 : 1)) attn_fwd_bf16_head_kern
   lsum += __shfl_xor(lsum, 32);
   if (query < S) {
     const float inv = 1.0f / lsum;
+    // log-sum-exp of the SCALED scores, for the backward of the training path: p = exp(scale (s - max)) sums to lsum
+    if (lse && half == 0) lse[(size_t)bh * S + query] = mx * kScale + __logf(lsum);
     unsigned short* orow = out + ((size_t)b * S + query) * D + h * HD;
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
@@ -424,12 +427,250 @@ __global__ void __launch_bounds__(64 * NB, (XQ ? 4 : 1)) attn_fwd_bf16_head_kern
 }
 
 template <int NB>
-void launch_head(const unsigned short* qkv, unsigned short* out, int B, int S, int H, int causal, hipStream_t st) {
-  if (causal) hipLaunchKernelGGL((attn_fwd_bf16_head_kernel<NB, true, false>), dim3(B * H), dim3(64 * NB), 0, st, qkv, out, S, H);
-  else hipLaunchKernelGGL((attn_fwd_bf16_head_kernel<NB, false, false>), dim3(B * H), dim3(64 * NB), 0, st, qkv, out, S, H);
+void launch_head(const unsigned short* qkv, unsigned short* out, int B, int S, int H, int causal, hipStream_t st,
+                 float* lse = nullptr) {
+  if (causal) hipLaunchKernelGGL((attn_fwd_bf16_head_kernel<NB, true, false>), dim3(B * H), dim3(64 * NB), 0, st, qkv, out, S, H, lse);
+  else hipLaunchKernelGGL((attn_fwd_bf16_head_kernel<NB, false, false>), dim3(B * H), dim3(64 * NB), 0, st, qkv, out, S, H, lse);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Backward of the whole-head kernel for SHORT sequences (S <= 64: the 50 tokens of ViT-B/32) on the bf16 MFMAs — the
+// training student of configs c3 / c5.  One workgroup (two waves) per (batch, head); Q, K, V, dO of the head are staged
+// in LDS once as bf16 tiles; scores, softmax and dS are fp32, P and dS are rounded to bf16 for the three products they feed,
+// dq / dk / dv leave as bf16 (the A operand of the qkv projection's data- and weight-gradient GEMMs).
+// There is no exchange between the waves after the staging barrier.  Wave w plays two roles:
+//   KEYS   32w..32w+31: for each query block, S = Q K^T and dP = dO V^T as C[query][key] — a lane owns ONE key column and 16
+//          queries in registers, which is the B operand of dV^T[d][key] = dO^T[d][q] P[q][key] and dK^T = Q^T dS when MFMA step
+//          t contracts the queries of registers 8t..8t+7 (the contraction order of a product is free; the A operands dO^T, Q^T
+//          come out of the row-major tiles through the transposing LDS read, as V^T does in the forward kernels);
+//   QUERIES 32w..32w+31: for each key block, S^T = K Q^T and dP^T = V dO^T as C[key][query] — a lane owns one query column
+//          (lse and delta are per-lane scalars) and its registers are the B operand of dQ^T[d][q] = K^T[d][key] dS^T[key][q].
+// S and dP are formed twice (once per layout): 8 extra MFMAs per block pair against an LDS transpose of dS and a second
+// barrier — at the bf16 rate the whole kernel is ~60 MFMAs per wave and is bound by its loads.
+template <bool CAUSAL>
+__global__ void __launch_bounds__(128) attn_bwd_bf16_kernel(const unsigned short* __restrict__ qkv, const unsigned short* __restrict__ out,
+                                                            const unsigned short* __restrict__ dout, const float* __restrict__ lse,
+                                                            unsigned short* __restrict__ dqkv, int S, int H) {
+  __shared__ __attribute__((aligned(16))) unsigned char Qs[64 * 128];
+  __shared__ __attribute__((aligned(16))) unsigned char Ks[64 * 128];
+  __shared__ __attribute__((aligned(16))) unsigned char Vs[64 * 128];
+  __shared__ __attribute__((aligned(16))) unsigned char dOs[64 * 128];
+  __shared__ float lse_s[64], dl_s[64];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, half = lane >> 5;
+  const int bh = blockIdx.x, b = bh / H, h = bh % H;
+  const int D = H * HD, ld = 3 * D;
+  const unsigned short* base = qkv + (size_t)b * S * ld + h * HD;
+  const unsigned short* obase = out + (size_t)b * S * D + h * HD;
+  const unsigned short* dobase = dout + (size_t)b * S * D + h * HD;
+
+  // ---- staging: 4 tiles x 64 rows x 8 granules over 128 threads = 4 granules per thread and tile, plus the O granules that
+  // pair with this thread's dO granules (delta = rowsum(O * dO)); every load is requested before the first is used (rows
+  // past the end read the last row and are zeroed)
+  {
+    u32x4 qv[4], kv[4], vv[4], dv[4], ov[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int id = tid + c * 128, rc = min(id >> 3, S - 1), g = id & 7;
+      qv[c] = *reinterpret_cast<const u32x4*>(base + (size_t)rc * ld + g * 8);
+      kv[c] = *reinterpret_cast<const u32x4*>(base + (size_t)rc * ld + D + g * 8);
+      vv[c] = *reinterpret_cast<const u32x4*>(base + (size_t)rc * ld + 2 * D + g * 8);
+      dv[c] = *reinterpret_cast<const u32x4*>(dobase + (size_t)rc * D + g * 8);
+      ov[c] = *reinterpret_cast<const u32x4*>(obase + (size_t)rc * D + g * 8);
+    }
+    if (tid < 64) lse_s[tid] = lse[(size_t)bh * S + min(tid, S - 1)];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int id = tid + c * 128, row = id >> 3, g = id & 7;
+      // delta: 8 elements here, the other 7 granules of the row sit in the 7 neighbouring lanes
+      float dl = 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const unsigned int o2 = ov[c][e], d2 = dv[c][e];
+        dl += __builtin_bit_cast(float, o2 << 16) * __builtin_bit_cast(float, d2 << 16);
+        dl += __builtin_bit_cast(float, o2 & 0xffff0000u) * __builtin_bit_cast(float, d2 & 0xffff0000u);
+      }
+      dl += __shfl_xor(dl, 1);
+      dl += __shfl_xor(dl, 2);
+      dl += __shfl_xor(dl, 4);
+      if (g == 0) dl_s[row] = row < S ? dl : 0.f;
+      if (row >= S) qv[c] = kv[c] = vv[c] = dv[c] = u32x4{0u, 0u, 0u, 0u};
+      *reinterpret_cast<u32x4*>(Qs + gran_off(row, g)) = qv[c];
+      *reinterpret_cast<u32x4*>(Ks + gran_off(row, g)) = kv[c];
+      *reinterpret_cast<u32x4*>(Vs + gran_off(row, g)) = vv[c];
+      *reinterpret_cast<u32x4*>(dOs + gran_off(row, g)) = dv[c];
+    }
+  }
+  __syncthreads();
+  const int nblk = (S + 31) >> 5;                   // 32-row blocks of queries = of keys (1 or 2)
+  if (wave >= nblk) return;                         // (no barrier below)
+
+  constexpr float c = kScale * 1.44269504088896341f;   // scale x log2(e)
+  constexpr float l2e = 1.44269504088896341f;
+  const int i16 = lane & 15, qq = i16 >> 2, pp = i16 & 3;
+  typedef short s16x8 __attribute__((ext_vector_type(8)));
+  // row fragment (A or B operand of a K = 64 contraction over head dims): X[row][16 s + 8 half .. +7], s = 0..3
+  auto row_frag = [&](const unsigned char* tile, int row, bf16x8 (&f)[4]) {
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) f[s4] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(tile + gran_off(row, 2 * s4 + half)));
+  };
+  auto mm4 = [&](const bf16x8 (&a)[4], const bf16x8 (&bq)[4]) {
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s4], bq[s4], acc, 0, 0, 0);
+    return acc;
+  };
+  // X^T fragments for a contraction over the 32 rows r0..r0+31 of a row-major tile: [t][dt] = X^T[32 dt + ..][the rows that MFMA
+  // step t contracts = r0 + 16 t + 4 half + (0..3) and + 8 + (0..3)] (see load_v in the forward kernel)
+  auto tr_frags = [&](const unsigned char* tile, int r0, s16x8 (&f)[2][2]) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int k0 = r0 + 16 * t + 4 * half;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        const int dcol = 32 * dt + 16 * ((lane >> 4) & 1) + 4 * pp;
+        const s16x4 lo = lds_tr16(tile + gran_off(k0 + qq, dcol >> 3) + (dcol & 7) * 2);
+        const s16x4 hi = lds_tr16(tile + gran_off(k0 + 8 + qq, dcol >> 3) + (dcol & 7) * 2);
+        f[t][dt] = s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      }
+    }
+  };
+  auto acc_xt = [&](f32x16 (&o)[2], const s16x8 (&xt)[2][2], const f32x16& w) {     // o[dt] += X^T (A) x w (B, rounded to bf16)
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      bf16x8 wf;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) wf[e] = (__bf16)w[8 * t + e];
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+        o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, xt[t][dt]), wf, o[dt], 0, 0, 0);
+    }
+  };
+  auto store_rows = [&](const f32x16 (&o)[2], int row, int part) {   // o[dt][4 j + e] = X[row][32 dt + 8 j + 4 half + e]
+    unsigned short* orow = dqkv + ((size_t)b * S + row) * ld + part * D + h * HD;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const u16x4 v = {bf16_bits(o[dt][4 * j + 0]), bf16_bits(o[dt][4 * j + 1]), bf16_bits(o[dt][4 * j + 2]), bf16_bits(o[dt][4 * j + 3])};
+        *reinterpret_cast<u16x4*>(orow + 32 * dt + 8 * j + 4 * half) = v;
+      }
+  };
+
+  // ---- role 1: this wave's KEYS (rows 32 wave + l31 of K and V), every query block -> dK, dV
+  {
+    const int key = 32 * wave + l31;
+    bf16x8 kf[4], vf[4];
+    row_frag(Ks, key, kf);
+    row_frag(Vs, key, vf);
+    f32x16 dk[2], dvv[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dk[dt][r] = dvv[dt][r] = 0.f;
+    for (int qb = CAUSAL ? wave : 0; qb < nblk; ++qb) {    // causal: query blocks before the key block hold no pair key <= query
+      bf16x8 qf[4], df[4];
+      row_frag(Qs, 32 * qb + l31, qf);
+      row_frag(dOs, 32 * qb + l31, df);
+      f32x16 st = mm4(qf, kf);                             // S[query][key]
+      f32x16 dp = mm4(df, vf);                             // dP[query][key]
+      s16x8 dot[2][2], qt[2][2];
+      tr_frags(dOs, 32 * qb, dot);
+      tr_frags(Qs, 32 * qb, qt);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int q = 32 * qb + (r & 3) + 8 * (r >> 2) + 4 * half;
+        const bool ok = q < S && key < S && (!CAUSAL || key <= q);
+        const float p = ok ? __builtin_amdgcn_exp2f(__builtin_fmaf(st[r], c, -lse_s[q] * l2e)) : 0.f;
+        st[r] = p;
+        dp[r] = p * (dp[r] - dl_s[q]) * kScale;            // dS
+      }
+      acc_xt(dvv, dot, st);                                // dV^T[d][key] += dO^T[d][q] P[q][key]
+      acc_xt(dk, qt, dp);                                  // dK^T[d][key] += Q^T[d][q] dS[q][key]
+    }
+    if (key < S) {
+      store_rows(dk, key, 1);
+      store_rows(dvv, key, 2);
+    }
+  }
+  // ---- role 2: this wave's QUERIES, every key block -> dQ
+  {
+    const int query = 32 * wave + l31;
+    bf16x8 qf[4], df[4];
+    row_frag(Qs, query, qf);
+    row_frag(dOs, query, df);
+    const float nl = -lse_s[query] * l2e, dl = dl_s[query];
+    f32x16 dq[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dq[dt][r] = 0.f;
+    const int nkb = CAUSAL ? wave + 1 : nblk;
+    for (int kb = 0; kb < nkb; ++kb) {
+      bf16x8 kf[4], vf[4];
+      row_frag(Ks, 32 * kb + l31, kf);
+      row_frag(Vs, 32 * kb + l31, vf);
+      f32x16 st = mm4(kf, qf);                             // S^T[key][query]
+      f32x16 dp = mm4(vf, df);                             // dP^T[key][query]
+      s16x8 kt[2][2];
+      tr_frags(Ks, 32 * kb, kt);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = 32 * kb + (r & 3) + 8 * (r >> 2) + 4 * half;
+        const bool ok = key < S && query < S && (!CAUSAL || key <= query);
+        const float p = ok ? __builtin_amdgcn_exp2f(__builtin_fmaf(st[r], c, nl)) : 0.f;
+        dp[r] = p * (dp[r] - dl) * kScale;                 // dS^T
+      }
+      acc_xt(dq, kt, dp);                                  // dQ^T[d][query] += K^T[d][key] dS^T[key][query]
+    }
+    if (query < S) store_rows(dq, query, 0);
+  }
 }
 
 }  // namespace
+
+// Training forms (bf16 student, configs c3 / c5): the forward also leaves the log-sum-exp of the scaled scores (S <= 288,
+// the whole-head kernel), the backward (S <= 64) returns dq | dk | dv as bf16 [B*S][3*H*64].
+DCLIP_API int dclip_attention_fwd_bf16_lse(const void* qkv, void* out, float* lse, int B, int S, int H, int causal, void* stream) {
+  DCLIP_REQUIRE(qkv && out && lse, "attention_fwd_bf16_lse: null pointer");
+  DCLIP_REQUIRE(B > 0 && S > 0 && S <= 288 && S != 257 && H > 0, "attention_fwd_bf16_lse: B=%d S=%d (<= 288, not 257) H=%d", B, S, H);
+  DCLIP_REQUIRE(((uintptr_t)qkv | (uintptr_t)out) % 16 == 0, "attention_fwd_bf16_lse: 16-byte alignment");
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned short* q = (const unsigned short*)qkv;
+  unsigned short* o = (unsigned short*)out;
+  switch (cdiv(S, 32)) {
+    case 1: launch_head<1>(q, o, B, S, H, causal, st, lse); break;
+    case 2: launch_head<2>(q, o, B, S, H, causal, st, lse); break;
+    case 3: launch_head<3>(q, o, B, S, H, causal, st, lse); break;
+    case 4: launch_head<4>(q, o, B, S, H, causal, st, lse); break;
+    case 5: launch_head<5>(q, o, B, S, H, causal, st, lse); break;
+    case 6: launch_head<6>(q, o, B, S, H, causal, st, lse); break;
+    case 7: launch_head<7>(q, o, B, S, H, causal, st, lse); break;
+    case 8: launch_head<8>(q, o, B, S, H, causal, st, lse); break;
+    default: launch_head<9>(q, o, B, S, H, causal, st, lse); break;
+  }
+  DCLIP_CHECK_LAUNCH("attention_fwd_bf16_lse");
+  return DCLIP_OK;
+}
+
+DCLIP_API int dclip_attention_bwd_bf16(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int B,
+                                       int S, int H, int causal, void* stream) {
+  DCLIP_REQUIRE(qkv && out && dout && lse && dqkv, "attention_bwd_bf16: null pointer");
+  DCLIP_REQUIRE(B > 0 && S > 0 && S <= 64 && H > 0, "attention_bwd_bf16: B=%d S=%d (<= 64) H=%d", B, S, H);
+  DCLIP_REQUIRE(((uintptr_t)qkv | (uintptr_t)out | (uintptr_t)dout | (uintptr_t)dqkv) % 16 == 0, "attention_bwd_bf16: 16-byte alignment");
+  hipStream_t st = (hipStream_t)stream;
+  if (causal)
+    hipLaunchKernelGGL((attn_bwd_bf16_kernel<true>), dim3(B * H), dim3(128), 0, st, (const unsigned short*)qkv,
+                       (const unsigned short*)out, (const unsigned short*)dout, lse, (unsigned short*)dqkv, S, H);
+  else
+    hipLaunchKernelGGL((attn_bwd_bf16_kernel<false>), dim3(B * H), dim3(128), 0, st, (const unsigned short*)qkv,
+                       (const unsigned short*)out, (const unsigned short*)dout, lse, (unsigned short*)dqkv, S, H);
+  DCLIP_CHECK_LAUNCH("attention_bwd_bf16");
+  return DCLIP_OK;
+}
 
 DCLIP_API int dclip_attention_fwd_bf16(const void* qkv, void* out, int B, int S, int H, int causal, void* stream) {
   DCLIP_REQUIRE(qkv && out, "attention_fwd_bf16: null pointer");

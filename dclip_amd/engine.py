@@ -416,16 +416,23 @@ def refresh_train_weights(cache: dict, layers: List[LayerParams], prefix: str = 
 
 def _attention_io16(M: int, S: int, D: int, I: int) -> bool:
     """Short sequences on the token-major backward schedule keep q/k/v, the attention output and their gradients in bf16
-    between the GEMMs and the attention kernels (fp32 arithmetic inside, ops.attention_*_io16): the qkv projection writes
-    bf16, no cast launches either side of the attention, half the bytes for kernels that are bound by them."""
+    between the GEMMs and the attention kernels: the qkv projection writes bf16, no cast launches either side of the
+    attention.  DCLIP_BF16_ATTN_IO16=0: fp32 attention I/O (casts) instead."""
     return S <= 64 and _tokmajor_wgrads(M, D, I) and os.environ.get("DCLIP_BF16_ATTN_IO16", "1") != "0"
+
+
+def _attention_mfma16() -> bool:
+    """Which kernels serve the bf16-I/O attention of the training student: the bf16 MFMA pair (ops.attention_fwd_bf16_lse /
+    attention_bwd_bf16: P and dS rounded to bf16 for the products they feed — the default) or, DCLIP_BF16_ATTN_MFMA=0, the
+    fp32-arithmetic kernels with bf16 loads and stores (ops.attention_*_io16)."""
+    return os.environ.get("DCLIP_BF16_ATTN_MFMA", "1") != "0"
 
 
 def layer_fwd_bf16_train(x, p: LayerParams, c: dict, pre: str, B: int, S: int, H: int, causal: bool, eps: float):
     ln1, m1, r1 = ops.layernorm_fwd_bf16(x, p.ln1_w, p.ln1_b, eps, save_stats=True)
     if _attention_io16(x.shape[0], S, x.shape[1], p.fc1_w.shape[0]):
         qkv = ops.gemm_bf16(ln1, _w16(c, pre + "qkv", p.qkv_w), bias=p.qkv_b, out_bf16=True)
-        attn16, lse = ops.attention_fwd_io16(qkv, B, S, H, causal)
+        attn16, lse = (ops.attention_fwd_bf16_lse if _attention_mfma16() else ops.attention_fwd_io16)(qkv, B, S, H, causal)
         attn = None
     else:
         qkv = ops.gemm_bf16(ln1, _w16(c, pre + "qkv", p.qkv_w), bias=p.qkv_b)        # fp32 out: the attention core is fp32
@@ -505,7 +512,8 @@ def layer_bwd_bf16_tokmajor(dx2, p: LayerParams, c: dict, pre: str, saved, B: in
     if qkv.dtype == torch.bfloat16:          # bf16 I/O attention: dO arrives as bf16, dq / dk / dv leave as bf16
         dattn16 = ops.gemm_bf16(dx1_16, _w16t(c, pre + "out", p.out_w), k=D, out_bf16=True)
         del dx1_16
-        dqkv16 = ops.attention_bwd_io16(qkv, attn16, dattn16, lse, B, S, H, causal)
+        dqkv16 = (ops.attention_bwd_bf16 if _attention_mfma16() else ops.attention_bwd_io16)(qkv, attn16, dattn16, lse, B, S, H,
+                                                                                             causal)
         del dattn16
         if need.get("qkv_b"):
             gr["qkv_b"] = ops.colsum_bf16(dqkv16, out=_galloc(alloc, "qkv_b", (3 * D,), dev))

@@ -737,6 +737,33 @@ def attention_fwd_bf16(qkv: torch.Tensor, B: int, S: int, H: int, causal: bool) 
     return out
 
 
+def attention_fwd_bf16_lse(qkv: torch.Tensor, B: int, S: int, H: int, causal: bool):
+    """bf16 MFMA attention forward that also returns the log-sum-exp (training): qkv [B*S, 3*H*64] bf16 -> (context bf16, lse fp32)."""
+    lib = _lib.load()
+    _bf16(qkv, "qkv")
+    if tuple(qkv.shape) != (B * S, 3 * H * 64):
+        raise ValueError(f"attention_fwd_bf16_lse: qkv shape {tuple(qkv.shape)} != {(B * S, 3 * H * 64)}")
+    out = torch.empty((B * S, H * 64), dtype=torch.bfloat16, device=qkv.device)
+    lse = torch.empty((B * H, S), dtype=torch.float32, device=qkv.device)
+    _lib.check(lib.dclip_attention_fwd_bf16_lse(qkv.data_ptr(), out.data_ptr(), lse.data_ptr(), B, S, H, int(causal), _stream()),
+               "attention_fwd_bf16_lse")
+    return out, lse
+
+
+def attention_bwd_bf16(qkv, out, dout, lse, B: int, S: int, H: int, causal: bool) -> torch.Tensor:
+    """Backward of attention_fwd_bf16_lse on the bf16 MFMAs (S <= 64): returns dqkv [B*S, 3*H*64] bf16."""
+    lib = _lib.load()
+    _bf16(qkv, "qkv"), _bf16(out, "out"), _bf16(dout, "dout"), _f32(lse, "lse")
+    D = H * 64
+    if tuple(qkv.shape) != (B * S, 3 * D) or tuple(out.shape) != (B * S, D) or tuple(dout.shape) != (B * S, D) \
+            or lse.numel() != B * H * S:
+        raise ValueError("attention_bwd_bf16: shape mismatch")
+    dqkv = torch.empty_like(qkv)
+    _lib.check(lib.dclip_attention_bwd_bf16(qkv.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(), dqkv.data_ptr(),
+                                            B, S, H, int(causal), _stream()), "attention_bwd_bf16")
+    return dqkv
+
+
 def attention_fwd_io16(qkv: torch.Tensor, B: int, S: int, H: int, causal: bool):
     """Short sequences (S <= 80), bf16 in / bf16 out, fp32 arithmetic: qkv [B*S, 3*H*64] bf16 -> (context bf16, lse fp32)."""
     lib = _lib.load()

@@ -346,6 +346,13 @@ int dclip_colsum_bf16(const void* X, float* out, int M, int N, int ldx, int accu
 /* Softmax attention of the frozen towers on bf16 q/k/v (the fused projection [B*S, 3*H*64] as written by
  * dclip_gemm_bf16 with out_bf16): fp32 scores / softmax, bf16 P and context [B*S, H*64].  Forward only. */
 int dclip_attention_fwd_bf16(const void* qkv, void* out, int B, int S, int H, int causal, void* stream);
+/* Training forms of the bf16 attention (the bf16 student of configs c3 / c5; eager_attention_forward, hf:modeling_clip.py:259-277,
+ * and its gradient): bf16 q/k/v, context, d(context) and dq|dk|dv; fp32 scores, softmax and dS; P and dS rounded to bf16 for
+ * the products they feed.  The forward (S <= 288, not 257) also writes lse [B*H][S] fp32 = log-sum-exp of the scaled scores;
+ * the backward (S <= 64) consumes it. */
+int dclip_attention_fwd_bf16_lse(const void* qkv, void* out, float* lse, int B, int S, int H, int causal, void* stream);
+int dclip_attention_bwd_bf16(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int B, int S,
+                             int H, int causal, void* stream);
 int dclip_layernorm_fwd_bf16(const float* x, const float* gamma, const float* beta, void* y, int rows, int D,
                              float eps, void* stream);
 

@@ -338,3 +338,47 @@ def test_mt_weights_bf16_equals_the_per_weight_kernels():
     table, n, tiles = ops.mt_weights_table([(w, None, only)])
     ops.mt_weights_bf16(table, n, tiles)
     assert torch.equal(only, ops.transpose_bf16(w))
+
+
+@pytest.mark.parametrize("B,S,H,causal", [(8, 50, 12, False), (3, 64, 2, False), (5, 17, 3, False), (4, 50, 8, True), (2, 1, 1, False),
+                                          (3, 33, 2, True)])
+def test_attention_bf16_mfma_training_pair(B, S, H, causal):
+    """bf16 MFMA attention forward (+ lse) and backward for the training student: against an fp64 attention of the same
+    bf16-valued operands and its autograd gradients, and against the fp32-arithmetic bf16-I/O kernels."""
+    from dclip_amd import ops
+    dev = torch.device("cuda:0")
+    D = 64 * H
+    qkv16 = (rnd((B * S, 3 * D), 21) * 1.5).to(torch.bfloat16).to(dev)
+    dout16 = rnd((B * S, D), 22).to(torch.bfloat16).to(dev)
+    out16, lse = ops.attention_fwd_bf16_lse(qkv16, B, S, H, causal)
+    assert torch.equal(out16, ops.attention_fwd_bf16(qkv16, B, S, H, causal))           # same kernel with / without the lse output
+    dq16 = ops.attention_bwd_bf16(qkv16, out16, dout16, lse, B, S, H, causal)
+    assert torch.equal(dq16, ops.attention_bwd_bf16(qkv16, out16, dout16, lse, B, S, H, causal))     # deterministic
+    # fp64 reference
+    x = qkv16.double().cpu().requires_grad_(True)
+    q, k, v = [t.reshape(B, S, H, 64).permute(0, 2, 1, 3) for t in x.split(D, dim=1)]
+    sc = q @ k.transpose(-1, -2) * 0.125
+    if causal:
+        sc = sc.masked_fill(torch.triu(torch.ones(S, S, dtype=torch.bool), 1), float("-inf"))
+    ref = (torch.softmax(sc, -1) @ v).permute(0, 2, 1, 3).reshape(B * S, D)
+    ref.backward(dout16.double().cpu())
+    ref_lse = torch.logsumexp(sc, -1).reshape(B * H, S)
+    assert float((lse.double().cpu() - ref_lse).abs().max()) < 2e-3
+    assert float((out16.double().cpu() - ref.detach()).abs().max() / ref.detach().abs().max()) < 1.5e-2
+    g, w = dq16.double().cpu(), x.grad
+    for part, name in enumerate(("dq", "dk", "dv")):
+        a, b_ = g[:, part * D:(part + 1) * D].reshape(-1), w[:, part * D:(part + 1) * D].reshape(-1)
+        if float(b_.abs().max()) < 1e-9:          # S = 1: the softmax is constant, dq = dk = 0 exactly; the kernel leaves rounding noise
+            assert float(a.abs().max()) < 1e-3, name
+            continue
+        cos = float(a @ b_ / (a.norm() * b_.norm()).clamp_min(1e-30))
+        rel = float((a - b_).abs().max() / b_.abs().max().clamp_min(1e-30))
+        assert cos > 0.9998 and rel < 3e-2, (name, cos, rel)
+    # and the fp32-arithmetic kernels on the same operands (they differ by the bf16 rounding of P and dS only)
+    o2, l2 = ops.attention_fwd_io16(qkv16, B, S, H, causal)
+    assert float((out16.float() - o2.float()).abs().max() / o2.float().abs().max()) < 1.5e-2
+    assert float((lse - l2.reshape(B * H, S)).abs().max()) < 2e-3
+    if S <= 64:
+        d2 = ops.attention_bwd_io16(qkv16, o2, dout16, l2, B, S, H, causal).float()[:, 2 * D:].reshape(-1)      # dv (never zero)
+        a = dq16.float()[:, 2 * D:].reshape(-1)
+        assert float(a @ d2 / (a.norm() * d2.norm())) > 0.9998
