@@ -171,7 +171,8 @@ def cpu_baseline(seconds: float = 12.0, regime: str = "north_star"):
                       f"(oracle/dclip_oracle.py, torch {torch.__version__} CPU)"}
 
 
-def build_workload(workload, model, teacher_model, batch_size, regions, student_precision, tower_precision, dev, group, rank):
+def build_workload(workload, model, teacher_model, batch_size, regions, student_precision, tower_precision, dev, group, rank,
+                   fast_teacher_init: bool = False):
     """The distillation module of one BASELINE config on synthetic inputs resident in HBM -> (module, student config, teacher
     config or None, batch).  c2: teacher image embedding given.  c3 / c5: the meta-teacher runs inside the step on `regions`
     crops per image through a separate frozen teacher CLIP."""
@@ -184,7 +185,10 @@ def build_workload(workload, model, teacher_model, batch_size, regions, student_
     tcfg = None
     if meta:
         tcfg = dcfg.NAMED[teacher_model or model]()
-        teacher_clip = from_hf_state_dict(tcfg, synth.synth_clip_state_dict(tcfg, seed=7), device=dev)
+        # (fast_teacher_init: the frozen teacher's random weights drawn on the GPU — the extra legs of the default run; a
+        # ViT-L/14 state dict takes ~10 s on the host)
+        teacher_clip = from_hf_state_dict(tcfg, synth.synth_clip_state_dict(tcfg, seed=7, device=dev if fast_teacher_init else None),
+                                          device=dev)
         for p_ in teacher_clip.parameters():
             p_.requires_grad = False
         E = tcfg.projection_dim               # a wider teacher is bridged to the student inside the module (c5)
@@ -227,13 +231,28 @@ def bf16_traffic():
     return json.load(open(path))["hbm_bytes_per_launch"] if os.path.exists(path) else None
 
 
-def extra_config_c3(dev, timer, steps: int = 5, warmup: int = 2):
-    """BASELINE config c3 AS QUOTED (ViT-B/32 student in bf16 + meta-teacher on 8 region crops per image through frozen bf16
-    towers, 256 pairs) timed for a few steps AFTER the contract's timed region, so that the driver's record carries the
-    bf16 configs' figures too (fwd + bwd + clip + AdamW, eager launches, HIP events on every bf16 GEMM launch)."""
+def extra_config(dev, timer, which: str, steps: int, warmup: int):
+    """One of the OTHER BASELINE configs timed for a few steps AFTER the contract's timed region, so that the driver's record
+    carries their figures too (fwd + bwd + clip + AdamW, eager launches):
+      "c3"  as quoted: ViT-B/32 student in bf16 + meta-teacher on 8 region crops per image through frozen bf16 towers, 256 pairs;
+      "c5"  one GPU's share: ViT-L/14 teacher towers (bf16) over the bf16 ViT-B/32 student through the declared bridge, 512 pairs;
+      "c4"  one GPU's share: ViT-B/16 distill step, fp32, 128 pairs (teacher image embedding given, as in c2).
+    `value` comes from `steps` steps WITHOUT per-launch events; the GEMM figure from two further steps with HIP events around
+    every GEMM launch (they cost ~3 % of a bf16 step)."""
     from dclip_amd import optim
-    B, R = 256, 8
-    module, cfg, tcfg, batch = build_workload("c3", "ViT-B/32", "ViT-B/32", B, R, "bf16", "bf16", dev, None, 0)
+    R = 8
+    if which == "c3":
+        B, spec, dtype = 256, ("c3", "ViT-B/32", "ViT-B/32", 256, R, "bf16", "bf16"), "bf16"
+        what = ("BASELINE config c3 as quoted: ViT-B/32 student bf16 (fp32 masters) + meta-teacher in the step (8 region crops/img "
+                "through a frozen ViT-B/32 tower, bf16 GEMM inputs), bs=256")
+    elif which == "c5":
+        B, spec, dtype = 512, ("c5", "ViT-B/32", "ViT-L/14", 512, R, "bf16", "bf16"), "bf16"
+        what = ("BASELINE config c5, one GPU's share (512 of the 4096 global pairs): ViT-B/32 student bf16 + meta-teacher on 8 region "
+                "crops/img through frozen ViT-L/14 towers (bf16 GEMM inputs), 768->512 teacher bridge, bs=512")
+    else:
+        B, spec, dtype = 128, ("c2", "ViT-B/16", None, 128, R, "fp32", "fp32"), "f32"
+        what = "BASELINE config c4, one GPU's share (128 of the 1024 global pairs): ViT-B/16 distill step, fp32, bs=128"
+    module, cfg, tcfg, batch = build_workload(*spec, dev, None, 0, fast_teacher_init=True)
     T = cfg.text.max_position_embeddings
     trainable = [p for p in module.parameters() if p.requires_grad]
     opt = optim.FusedAdamW(trainable, lr=1e-6, max_grad_norm=0.5)
@@ -254,31 +273,42 @@ def extra_config_c3(dev, timer, steps: int = 5, warmup: int = 2):
         last = one()
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
-    # the bf16 GEMM figure from two MORE steps with HIP events around every bf16 GEMM launch (the events cost ~3 % of such a
-    # step, so they stay outside the steps `value` is taken from)
-    ev_steps = 2
+    ev_steps = 2 if which != "c5" else 1
     timer.records16.clear()
+    timer.records.clear()
     timer.enabled = True
     for _ in range(ev_steps):
         one()
     torch.cuda.synchronize()
     timer.enabled = False
-    f16, ms16, n16 = timer.summary(bf16=True)
     ms = el * 1e3 / steps
-    floor_ms = (step_flops_per_image(cfg, T) * B + meta_teacher_flops(cfg, tcfg, B, R, T)) / 2500.0 / 1e9
-    out = {"workload": "BASELINE config c3 as quoted: ViT-B/32 student bf16 (fp32 masters) + meta-teacher in the step (8 region "
-                       "crops/img through a frozen ViT-B/32 tower, bf16 GEMM inputs), bs=256, fwd+bwd + clip-norm 0.5 + AdamW, "
-                       "eager launches; roofline_bf16 from two further steps with HIP events around every bf16 GEMM launch",
+    student_flops = step_flops_per_image(cfg, T) * B
+    out = {"workload": what + ", fwd+bwd + clip-norm 0.5 + AdamW, eager launches; the GEMM roofline from further steps with HIP "
+                              "events around every GEMM launch",
            "value": round(B * steps / el, 2), "unit": "images/s", "ms_per_step": round(ms, 3), "steps": steps, "warmup": warmup,
-           "dtype": "bf16", "loss": float(last),
-           "roofline_bf16": {"bound": "mfma", "kernel": "gemm_bf16_pp_kernel (v_mfma_f32_16x16x32_bf16)",
-                             "achieved": round(f16 / (ms16 * 1e-3) / 1e12, 2) if ms16 else None, "peak": 2500.0, "unit": "TFLOP/s",
-                             "frac": round(f16 / (ms16 * 1e-3) / 1e12 / 2500.0, 4) if ms16 else None,
-                             "launches_per_step": n16 // ev_steps, "gemm_ms_per_step": round(ms16 / ev_steps, 3),
-                             "traffic": bf16_traffic()},
-           "roofline_step": {"bound": "mfma", "unit": "ms", "floor_ms": round(floor_ms, 3), "frac": round(floor_ms / ms, 4),
-                             "peak_tflops": 2500.0}}
-    del module, opt, batch
+           "dtype": dtype, "loss": float(last)}
+    if dtype == "bf16":
+        f16, ms16, n16 = timer.summary(bf16=True)
+        floor_ms = (student_flops + meta_teacher_flops(cfg, tcfg, B, R, T)) / 2500.0 / 1e9
+        out["roofline_bf16"] = {"bound": "mfma", "kernel": "gemm_bf16_pp_kernel (v_mfma_f32_16x16x32_bf16)",
+                                "achieved": round(f16 / (ms16 * 1e-3) / 1e12, 2) if ms16 else None, "peak": 2500.0,
+                                "unit": "TFLOP/s", "frac": round(f16 / (ms16 * 1e-3) / 1e12 / 2500.0, 4) if ms16 else None,
+                                "launches_per_step": n16 // ev_steps, "gemm_ms_per_step": round(ms16 / ev_steps, 3),
+                                "traffic": bf16_traffic() if which == "c3" else None}
+        out["roofline_step"] = {"bound": "mfma", "unit": "ms", "floor_ms": round(floor_ms, 3), "frac": round(floor_ms / ms, 4),
+                                "peak_tflops": 2500.0}
+    else:
+        f32, ms32, n32 = timer.summary()
+        out["roofline"] = {"bound": "mfma", "kernel": "gemm_f32_kernel (v_mfma_f32_32x32x2_f32)",
+                           "achieved": round(f32 / (ms32 * 1e-3) / 1e12, 2) if ms32 else None, "peak": PEAK_F32_MFMA_TFLOPS,
+                           "unit": "TFLOP/s", "frac": round(f32 / (ms32 * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4) if ms32 else None,
+                           "launches_per_step": n32 // ev_steps, "gemm_ms_per_step": round(ms32 / ev_steps, 3)}
+        out["roofline_step"] = {"bound": "mfma", "achieved": round(student_flops / (ms * 1e-3) / 1e12, 2), "peak": PEAK_F32_MFMA_TFLOPS,
+                                "unit": "TFLOP/s", "frac": round(student_flops / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                                "flops_per_image": step_flops_per_image(cfg, T)}
+    del module, opt, batch, trainable
+    import gc
+    gc.collect()
     torch.cuda.empty_cache()
     return out
 
@@ -702,13 +732,18 @@ def main():
                                 embedding_all_gather_bytes_per_rank=2 * B * cfg.projection_dim * 4)
         if world == 1 and not meta and not args.no_extra_legs and args.student_precision == "fp32" \
                 and cfg.name == "ViT-B/32" and B == 256 and not args.no_gemm_events:
-            # the default run also times the bf16 config c3 for a few steps (outside the contract's timed region)
-            try:
-                line["extra_configs"] = {"c3_bf16": extra_config_c3(dev, timer)}
-            except Exception as exc:          # informative only: never fail the bench line on it
-                line["extra_configs"] = {"c3_bf16": {"error": f"{type(exc).__name__}: {exc}"[:300]}}
+            # the default run also times the other BASELINE configs for a few steps each (outside the contract's timed region):
+            # c3 as quoted, and one GPU's share of the 8-GPU configs c4 and c5
+            line["extra_configs"] = {}
+            for name, which, st_, wu_ in (("c3_bf16", "c3", 5, 2), ("c4_per_gpu", "c4", 3, 1), ("c5_per_gpu_bf16", "c5", 3, 1)):
+                if os.environ.get("DCLIP_BENCH_EXTRA", "c3,c4,c5").find(which) < 0:
+                    continue
+                try:
+                    line["extra_configs"][name] = extra_config(dev, timer, which, st_, wu_)
+                except Exception as exc:          # informative only: never fail the bench line on it
+                    line["extra_configs"][name] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
         if world == 1 and not args.no_cpu_baseline:
-            secs = float(os.environ.get("DCLIP_BENCH_CPU_SECONDS", "12"))
+            secs = float(os.environ.get("DCLIP_BENCH_CPU_SECONDS", "10"))
             line["cpu_baseline"] = cpu_baseline(secs, "north_star")          # same regime as `value`
             line["cpu_baseline_c1"] = cpu_baseline(secs, "as_written")       # BASELINE config c1 as the reference runs it
         print(json.dumps(line), flush=True)

@@ -15,7 +15,7 @@ from .config import ClipConfig, VisionConfig, TextConfig
 
 
 def _normal(gen, shape, std):
-    return torch.randn(shape, generator=gen, dtype=torch.float32) * std
+    return torch.randn(shape, generator=gen, dtype=torch.float32, device=gen.device) * std
 
 
 def _tower_layers(sd, gen, prefix, hidden, inter, n_layers, jitter):
@@ -37,14 +37,17 @@ def _tower_layers(sd, gen, prefix, hidden, inter, n_layers, jitter):
         sd[f"{p}.mlp.fc2.bias"] = _normal(gen, (hidden,), jitter)
 
 
-def synth_clip_state_dict(cfg: ClipConfig, seed: int = 0, jitter: float = 0.02, gain: float = 1.0):
+def synth_clip_state_dict(cfg: ClipConfig, seed: int = 0, jitter: float = 0.02, gain: float = 1.0, device=None):
     """HF-keyed fp32 state dict for `cfg` (keys: SURVEY.md §8b-keys).
+
+    `device`: draw on that device with ITS generator (seconds faster for ViT-L/14's 428 M parameters) — same shapes and
+    stds, but NOT the values of the CPU draw that fixtures and tests are keyed to: for benchmarks of frozen towers only.
 
     `jitter` perturbs biases / LayerNorm affine params away from HF's 0/1 init so
     parity tests exercise them.  `gain` scales the q/k/v/fc weights: the HF init is
     so small that attention is near-uniform; tests use gain>1 to get peaked softmax.
     """
-    gen = torch.Generator().manual_seed(seed)
+    gen = (torch.Generator() if device is None else torch.Generator(device=device)).manual_seed(seed)
     v, t = cfg.vision, cfg.text
     sd = {}
     sd["logit_scale"] = torch.tensor(cfg.logit_scale_init_value, dtype=torch.float32)
