@@ -464,6 +464,40 @@ def _tokmajor_wgrads(M: int, D: int, I: int) -> bool:
     return hit
 
 
+_WGRAD_STREAMS: Dict[int, "torch.cuda.Stream"] = {}
+
+
+class _SideWgrads:
+    """The four weight-gradient GEMMs of a layer on a SECOND stream beside the data-gradient chain (DCLIP_BF16_WGRAD_STREAM=0
+    keeps them on the main stream).  A bf16 ping-pong GEMM takes a whole CU per workgroup, and the student's data-gradient
+    GEMMs have 150 tiles for 256 CUs: the weight gradient of the same dY (independent of everything downstream) takes the
+    idle CUs — same box, alternating: c3 43.83 -> 43.28 ms, the c2-shaped bf16 step under graph replay 16.78 -> 16.48 ms,
+    results bit-identical.  (For the fp32 GEMMs, three workgroups per CU sharing the matrix pipe, the same idea measured
+    SLOWER in round 2: there is no idle CU to take.)  Fork: the side stream waits for the main stream (dY is ready); join at the end of the layer.  Operands
+    are kept alive until the join (the caching allocator would hand a freed block to the main stream while the side
+    stream still reads it); scratch comes from a workspace lane of its own."""
+
+    def __init__(self, dev):
+        self.on = os.environ.get("DCLIP_BF16_WGRAD_STREAM", "1") != "0" and dev.type == "cuda"
+        self.keep = []
+        if self.on:
+            self.main = torch.cuda.current_stream(dev)
+            self.side = _WGRAD_STREAMS.setdefault(dev.index, torch.cuda.Stream(device=dev))
+
+    def run(self, fn, *operands):
+        if not self.on:
+            return fn()
+        self.keep.extend(operands)
+        self.side.wait_stream(self.main)
+        with torch.cuda.stream(self.side), ops.workspace_lane(2):
+            return fn()
+
+    def join(self):
+        if self.on:
+            self.main.wait_stream(self.side)
+            self.keep.clear()
+
+
 def layer_bwd_bf16_tokmajor(dx2, p: LayerParams, c: dict, pre: str, saved, B: int, S: int, H: int, causal: bool,
                             need: Dict[str, bool], alloc=None, dx2_16=None, fc2_b=None, below_fc2_b=None, want_dx16=False):
     """layer_bwd_bf16 with the weight gradients read from the operands as they lie — dW = dY^T X on the token-major form of
@@ -479,18 +513,21 @@ def layer_bwd_bf16_tokmajor(dx2, p: LayerParams, c: dict, pre: str, saved, B: in
     I = g16.shape[1]
     dev = x.device
     gr: Dict[str, torch.Tensor] = {}
+    wg = _SideWgrads(dev)
     # ---- fc2
     if dx2_16 is None:
         dx2_16 = ops.cast_bf16(dx2)
     if need.get("fc2_w"):
-        gr["fc2_w"] = ops.gemm_bf16_wgrad_tokmajor(dx2_16, g16, out=_galloc(alloc, "fc2_w", (D, I), dev))
+        o_ = _galloc(alloc, "fc2_w", (D, I), dev)
+        gr["fc2_w"] = wg.run(lambda a_=dx2_16, b_=g16: ops.gemm_bf16_wgrad_tokmajor(a_, b_, out=o_), dx2_16, g16)
     if need.get("fc2_b"):
         gr["fc2_b"] = fc2_b if fc2_b is not None else ops.colsum(dx2, out=_galloc(alloc, "fc2_b", (D,), dev))
     dh16 = ops.gemm_bf16(dx2_16, _w16t(c, pre + "fc2", p.fc2_w), k=D, dgelu_of=h16, out_bf16=True)       # [M, I]
     del dx2_16
     # ---- fc1
     if need.get("fc1_w"):
-        gr["fc1_w"] = ops.gemm_bf16_wgrad_tokmajor(dh16, ln2, out=_galloc(alloc, "fc1_w", (I, D), dev))
+        o1_ = _galloc(alloc, "fc1_w", (I, D), dev)
+        gr["fc1_w"] = wg.run(lambda a_=dh16, b_=ln2: ops.gemm_bf16_wgrad_tokmajor(a_, b_, out=o1_), dh16, ln2)
     if need.get("fc1_b"):
         gr["fc1_b"] = ops.colsum_bf16(dh16, out=_galloc(alloc, "fc1_b", (I,), dev))
     dln2 = ops.gemm_bf16(dh16, _w16t(c, pre + "fc1", p.fc1_w), k=dh16.shape[1])                          # [M, D] fp32
@@ -508,7 +545,8 @@ def layer_bwd_bf16_tokmajor(dx2, p: LayerParams, c: dict, pre: str, saved, B: in
         gr["out_b"] = out_b
     # ---- out_proj
     if need.get("out_w"):
-        gr["out_w"] = ops.gemm_bf16_wgrad_tokmajor(dx1_16, attn16, out=_galloc(alloc, "out_w", (D, D), dev))
+        o2_ = _galloc(alloc, "out_w", (D, D), dev)
+        gr["out_w"] = wg.run(lambda a_=dx1_16, b_=attn16: ops.gemm_bf16_wgrad_tokmajor(a_, b_, out=o2_), dx1_16, attn16)
     if qkv.dtype == torch.bfloat16:          # bf16 I/O attention: dO arrives as bf16, dq / dk / dv leave as bf16
         dattn16 = ops.gemm_bf16(dx1_16, _w16t(c, pre + "out", p.out_w), k=D, out_bf16=True)
         del dx1_16
@@ -527,7 +565,8 @@ def layer_bwd_bf16_tokmajor(dx2, p: LayerParams, c: dict, pre: str, saved, B: in
         del dqkv
     # ---- qkv projection
     if need.get("qkv_w"):
-        gr["qkv_w"] = ops.gemm_bf16_wgrad_tokmajor(dqkv16, ln1, out=_galloc(alloc, "qkv_w", (3 * D, D), dev))
+        o3_ = _galloc(alloc, "qkv_w", (3 * D, D), dev)
+        gr["qkv_w"] = wg.run(lambda a_=dqkv16, b_=ln1: ops.gemm_bf16_wgrad_tokmajor(a_, b_, out=o3_), dqkv16, ln1)
     dln1 = ops.gemm_bf16(dqkv16, _w16t(c, pre + "qkv", p.qkv_w), k=3 * D)
     del dqkv16
     want_ln1 = bool(need.get("ln1_w") or need.get("ln1_b"))
@@ -538,6 +577,7 @@ def layer_bwd_bf16_tokmajor(dx2, p: LayerParams, c: dict, pre: str, saved, B: in
     dx, dg, db = res[0], res[1], res[2]
     if want_ln1:
         gr["ln1_w"], gr["ln1_b"] = dg, db
+    wg.join()                                  # the weight gradients are final before the caller reports / reduces them
     return dx, (res[3] if want_dx16 else None), gr
 
 
