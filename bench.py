@@ -66,6 +66,32 @@ def step_flops_per_image(cfg, T) -> float:
     return 3.0 * fv + ft
 
 
+class single_stream:
+    """Steps whose GEMM launches are bracketed by HIP events run every kernel ALONE on one stream: the second streams of the
+    step (the meta-teacher beside the student's forward, the weight-gradient GEMMs beside the data-gradient chain, the frozen
+    text tower) are switched off for them, so that a per-launch duration is that of the kernel, not of the kernel sharing the
+    chip with another stream's work.  `value` comes from steps with the second streams on."""
+
+    def __init__(self, module, on: bool = True):
+        self.module, self.on = module, on
+
+    def __enter__(self):
+        if self.on:
+            self.prev = (self.module.overlap_teacher, os.environ.get("DCLIP_BF16_WGRAD_STREAM"))
+            self.module.overlap_teacher = False
+            os.environ["DCLIP_BF16_WGRAD_STREAM"] = "0"
+        return self
+
+    def __exit__(self, *exc):
+        if self.on:
+            self.module.overlap_teacher = self.prev[0]
+            if self.prev[1] is None:
+                os.environ.pop("DCLIP_BF16_WGRAD_STREAM", None)
+            else:
+                os.environ["DCLIP_BF16_WGRAD_STREAM"] = self.prev[1]
+        return False
+
+
 class GemmTimer:
     """HIP events around every dclip_gemm_f32 launch, on the stream the kernels are launched on (torch's current
     stream — torch.cuda.Event records there).  Sum(flops) / Sum(elapsed) over the timed region is the roofline
@@ -277,9 +303,10 @@ def extra_config(dev, timer, which: str, steps: int, warmup: int):
     timer.records16.clear()
     timer.records.clear()
     timer.enabled = True
-    for _ in range(ev_steps):
-        one()
-    torch.cuda.synchronize()
+    with single_stream(module):
+        for _ in range(ev_steps):
+            one()
+        torch.cuda.synchronize()
     timer.enabled = False
     ms = el * 1e3 / steps
     student_flops = step_flops_per_image(cfg, T) * B
@@ -459,6 +486,10 @@ def main():
     # region launched eagerly so that the GEMM launches of that step can be bracketed by HIP events.
     hybrid = None
     exec_note = "eager launches"
+    if meta:
+        exec_note = ("eager launches; the meta-teacher on a second stream beside the student's image forward"
+                     + (", the bf16 weight-gradient GEMMs beside the data-gradient chain" if args.student_precision == "bf16" else "")
+                     + "; the steps sampled for per-launch GEMM events launch every kernel alone on one stream")
     if graphed is None and world == 1 and not meta and not args.eager and opt is not None:
         try:
             from dclip_amd.graph import GraphedStep
@@ -548,7 +579,8 @@ def main():
         timer.enabled = on
         sampled["n"] += int(on)
         sampled["i"] += 1
-        out_ = step(eager_now=on)
+        with single_stream(module, on):          # event-bracketed steps launch every kernel alone on one stream
+            out_ = step(eager_now=on)
         note(f"timed step {sampled['i'] - 1} launched")
         return out_
 
@@ -743,7 +775,7 @@ def main():
                 except Exception as exc:          # informative only: never fail the bench line on it
                     line["extra_configs"][name] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
         if world == 1 and not args.no_cpu_baseline:
-            secs = float(os.environ.get("DCLIP_BENCH_CPU_SECONDS", "10"))
+            secs = float(os.environ.get("DCLIP_BENCH_CPU_SECONDS", "8"))
             line["cpu_baseline"] = cpu_baseline(secs, "north_star")          # same regime as `value`
             line["cpu_baseline_c1"] = cpu_baseline(secs, "as_written")       # BASELINE config c1 as the reference runs it
         print(json.dumps(line), flush=True)
