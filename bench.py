@@ -237,6 +237,9 @@ def build_workload(workload, model, teacher_model, batch_size, regions, student_
     }
     if meta:
         batch["regions"] = synth.synth_regions(batch_size, regions, tcfg.vision, seed=2000 + rank).to(dev)
+        # token-padding size of the batch, known on the host (the reference sizes it from the caption strings): the synthetic
+        # captions are 77 tokens long = 75 word tokens; with it the teacher never synchronises the host with the stream
+        batch["max_tokens"] = int((batch["input_ids"] == cfg.text.eos_token_id).int().argmax(dim=1).max()) - 1
     else:
         batch["teacher_image_emb"] = synth.synth_embeddings(batch_size, cfg.projection_dim, seed=1000 + rank).to(dev)
     return module, cfg, tcfg, batch
@@ -283,20 +286,24 @@ def extra_config(dev, timer, which: str, steps: int, warmup: int):
     trainable = [p for p in module.parameters() if p.requires_grad]
     opt = optim.FusedAdamW(trainable, lr=1e-6, max_grad_norm=0.5)
 
-    def one():
+    prefetch_ok = which != "c4" and os.environ.get("DCLIP_TEACHER_PREFETCH", "1") != "0"
+
+    def one(prefetch=False):
         loss = module.training_step(batch)
+        if prefetch:
+            module.prefetch_teacher(batch)       # the next step's teacher beside this step's backward (see step() in main)
         loss.backward()
         opt.step()
         opt.zero_grad(set_to_none=True)
         return loss.detach()
 
-    for _ in range(warmup):
-        one()
+    for k_ in range(warmup):
+        one(prefetch_ok and k_ + 1 < warmup)
     timer.enabled = False
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(steps):
-        last = one()
+    for k_ in range(steps):
+        last = one(prefetch_ok and k_ + 1 < steps)      # exactly K teacher passes inside the K timed steps
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     ev_steps = 2 if which != "c5" else 1
@@ -487,7 +494,9 @@ def main():
     hybrid = None
     exec_note = "eager launches"
     if meta:
-        exec_note = ("eager launches; the meta-teacher on a second stream beside the student's image forward"
+        exec_note = ("eager launches; the meta-teacher on a second stream — step n+1's teacher is started after step n's forward and "
+                     "runs beside its backward, optimizer and the next student forward (one teacher pass per step; a step next "
+                     "to an event-sampled one runs its teacher in the step, beside the student's image forward)"
                      + (", the bf16 weight-gradient GEMMs beside the data-gradient chain" if args.student_precision == "bf16" else "")
                      + "; the steps sampled for per-launch GEMM events launch every kernel alone on one stream")
     if graphed is None and world == 1 and not meta and not args.eager and opt is not None:
@@ -511,6 +520,11 @@ def main():
             for p_ in trainable:
                 p_.grad = None
 
+    # meta-teacher workloads: the teacher of step n+1 is launched during step n (set per step by the loops below: never
+    # ahead of a step whose GEMM launches are bracketed by events — that one runs its own teacher, alone on one stream)
+    prefetch_ok = meta and os.environ.get("DCLIP_TEACHER_PREFETCH", "1") != "0"
+    prefetch_next = {"on": False}
+
     def step(with_opt=True, eager_now=False):
         if hybrid is not None and not eager_now:
             for p_, g_ in hybrid_grads:          # an eager step in between left .grad at None
@@ -528,6 +542,11 @@ def main():
                 opt.step()                       # gradients stay allocated in the graph's pool: no zero_grad
             return loss
         loss = module.training_step(batch)      # N > 1: this rank's share of the global loss (dist.py)
+        if prefetch_next["on"]:
+            # the NEXT step's meta-teacher (the same synthetic batch) is started now, on its own stream: it runs beside this
+            # step's backward + optimizer and the next step's student forward (CLIPImageDistillation.prefetch_teacher).
+            # Every step still contains exactly one teacher pass and one student pass.
+            module.prefetch_teacher(batch)
         loss.backward()
         if sync is not None:
             sync.finish()
@@ -564,6 +583,7 @@ def main():
 
     note("model + batch resident; warm-up starts")
     for i_ in range(args.warmup):
+        prefetch_next["on"] = prefetch_ok and i_ + 1 < args.warmup       # (timed step 0 is an event-bracketed one)
         step()
         note(f"warm-up step {i_} launched")
     if sync is not None:
@@ -579,6 +599,8 @@ def main():
         timer.enabled = on
         sampled["n"] += int(on)
         sampled["i"] += 1
+        next_on = graphed is None and not args.no_gemm_events and sampled["i"] % stride == 0
+        prefetch_next["on"] = prefetch_ok and not on and not next_on and sampled["i"] < args.steps
         with single_stream(module, on):          # event-bracketed steps launch every kernel alone on one stream
             out_ = step(eager_now=on)
         note(f"timed step {sampled['i'] - 1} launched")

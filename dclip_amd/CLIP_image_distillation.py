@@ -94,6 +94,7 @@ class CLIPImageDistillation(LightningLikeModule):
         # losses bit-identical.  None = on (DCLIP_TEACHER_STREAM=0 switches it off); not inside a HIP-graph capture.
         self.overlap_teacher = None
         self._teacher_stream = None
+        self._prefetched = None          # (key, teacher image target, teacher sentence embedding) of prefetch_teacher()
         self.save_hyperparameters(hparams, ignore="clip_model")
         self.student = _as_hip_model(clip_model)
         self.preprocess = clip_preprocess
@@ -173,6 +174,58 @@ class CLIPImageDistillation(LightningLikeModule):
             raise RuntimeError("caption strings need clip_preprocess (an HF CLIPProcessor loaded from a local path)")
         return self.preprocess(text=captions, return_tensors="pt", padding=True, truncation=True)["input_ids"]
 
+    @staticmethod
+    def _batch_key(batch):
+        r, t = batch["regions"], batch["input_ids"]
+        return (r.data_ptr(), tuple(r.shape), r._version, t.data_ptr(), tuple(t.shape), t._version)
+
+    def prefetch_teacher(self, batch) -> bool:
+        """Start the meta-teacher for a tensor batch that will be passed to `training_step` LATER (software pipelining across
+        steps: the teacher is frozen, its targets do not depend on the student's update).  Call it between
+        `training_step(current)` and `loss.backward()` with the NEXT batch: the teacher's stream forks after the current
+        forward, so the teacher's ~20 ms of work run beside the current backward, the optimizer and the next step's student
+        forward — all of which leave CUs idle (150-tile GEMMs, LayerNorm / attention launches) — and `training_step(next)`
+        joins it just before the loss.  Refused (False) when the teacher reads weights that are being trained (`_teacher_frozen`).
+        Batches that carry `max_tokens` (token-padding size, known on the host) avoid the
+        one host sync inside the teacher.  Returns False (nothing started) for batches without `regions`, on the CPU, inside a
+        HIP-graph capture, or when second streams are switched off."""
+        if not (isinstance(batch, dict) and "regions" in batch and "teacher_image_emb" not in batch):
+            return False
+        import os
+        dev = self.device
+        if dev.type != "cuda" or torch.cuda.is_current_stream_capturing() or os.environ.get("DCLIP_TEACHER_PREFETCH", "1") == "0":
+            return False
+        if self.overlap_teacher is False or os.environ.get("DCLIP_TEACHER_STREAM") == "0":
+            return False
+        if not self._teacher_frozen():
+            return False
+        from . import ops
+        regions, tokens = batch["regions"].to(dev), batch["input_ids"].to(dev)
+        main = torch.cuda.current_stream(dev)
+        if self._teacher_stream is None:
+            self._teacher_stream = torch.cuda.Stream(device=dev)
+        self._teacher_stream.wait_stream(main)                       # fork behind what is queued now (the current forward)
+        with torch.cuda.stream(self._teacher_stream), torch.no_grad(), ops.workspace_lane(3):
+            target = self.teacher.compute_global_embedding_tensors(regions, tokens, batch.get("region_counts"),
+                                                                   batch.get("max_tokens")).float()
+            sentence = self.teacher.last_sentence_embedding
+        self._prefetched = (self._batch_key(batch), target, sentence, regions, tokens)
+        return True
+
+    def _teacher_frozen(self) -> bool:
+        """True when nothing the teacher reads is being trained: its cross-modal block and BOTH towers of its CLIP.  A
+        teacher built on the student's own model (the towers shared) reads weights the optimizer is about to change — its
+        targets for batch n+1 then depend on update n, and starting it early would read them before (or while) they are
+        written."""
+        clip = getattr(self.teacher, "_clip", None)
+        towers = clip.parameters() if clip is not None else ()
+        return not any(p.requires_grad for p in self.teacher.parameters()) and not any(p.requires_grad for p in towers)
+
+    def _drop_prefetched(self) -> bool:
+        """A prefetched target that is not this batch's (the loop skipped a batch) is released; always False."""
+        self._prefetched = None
+        return False
+
     def _teacher_beside_student(self, images) -> bool:
         import os
         on = self.overlap_teacher
@@ -204,7 +257,21 @@ class CLIPImageDistillation(LightningLikeModule):
                 if "teacher_image_emb" in batch:
                     teacher_image = batch["teacher_image_emb"].to(dev).float()
                     ran_teacher = False
-                elif self._teacher_beside_student(images):
+                elif self._prefetched is not None and self._prefetched[0] == self._batch_key(batch):
+                    # the teacher of THIS batch was started by prefetch_teacher() during the previous step: launch the student's
+                    # forward, then join the teacher's stream
+                    _key, teacher_image, sentence, _r, _t = self._prefetched
+                    self._prefetched = None
+                    main = torch.cuda.current_stream(dev)
+                    with torch.set_grad_enabled(grad_on):
+                        early_student_image = self.student.get_image_features(
+                            pixel_values=images, precision=self.student_precision).float()
+                    main.wait_stream(self._teacher_stream)                       # join
+                    teacher_image.record_stream(main)
+                    self.teacher.last_sentence_embedding = sentence
+                    if sentence is not None:
+                        sentence.record_stream(main)
+                elif self._drop_prefetched() or self._teacher_beside_student(images):
                     # student image forward FIRST (asynchronous, main stream), then the teacher on its own stream: a host
                     # sync inside the teacher (token-padding size) then waits for the teacher's stream only
                     from . import ops
@@ -218,14 +285,14 @@ class CLIPImageDistillation(LightningLikeModule):
                             pixel_values=images, precision=self.student_precision).float()
                     with torch.cuda.stream(self._teacher_stream), ops.workspace_lane(3):
                         teacher_image = self.teacher.compute_global_embedding_tensors(
-                            regions, tokens, batch.get("region_counts")).float()
+                            regions, tokens, batch.get("region_counts"), batch.get("max_tokens")).float()
                     main.wait_stream(self._teacher_stream)                       # join
                     teacher_image.record_stream(main)
                     if self.teacher.last_sentence_embedding is not None:
                         self.teacher.last_sentence_embedding.record_stream(main)
                 else:
                     teacher_image = self.teacher.compute_global_embedding_tensors(
-                        batch["regions"].to(dev), tokens, batch.get("region_counts")).float()
+                        batch["regions"].to(dev), tokens, batch.get("region_counts"), batch.get("max_tokens")).float()
                 teacher_text = batch["teacher_text_emb"].to(dev).float() if "teacher_text_emb" in batch else None
         else:
             images, captions, image_paths, weighted_boxes_batch = batch

@@ -89,8 +89,11 @@ def checkpoint_filename(epoch: int, train_loss: float) -> str:
     return f"epoch-epoch={epoch:02d}-train_loss={train_loss:.2f}.ckpt"
 
 
-def _with_last_flag(iterable):
-    """(index, item, is_last) with one item of look-ahead (loaders without __len__ work too)."""
+_END = object()
+
+
+def _with_lookahead(iterable):
+    """(index, item, next item or _END) with one item of look-ahead (loaders without __len__ work too)."""
     it = iter(iterable)
     try:
         prev = next(it)
@@ -98,10 +101,10 @@ def _with_last_flag(iterable):
         return
     i = 0
     for cur in it:
-        yield i, prev, False
+        yield i, prev, cur
         prev = cur
         i += 1
-    yield i, prev, True
+    yield i, prev, _END
 
 
 class Trainer:
@@ -189,6 +192,7 @@ class Trainer:
             model.val_dataloader() if hasattr(model, "val_dataloader") else None)
         step = 0
         graphed, acc, gparams = None, None, None
+        prefetch = getattr(model, "prefetch_teacher", None)      # cross-step pipelining of a frozen teacher, where the module has it
         for epoch in range(self.max_epochs):
             model.current_epoch = epoch
             model.train()
@@ -202,7 +206,8 @@ class Trainer:
             if group is not None and getattr(train, "rank_sharded", False) and hasattr(getattr(train, "sampler", None), "set_epoch"):
                 train.sampler.set_epoch(epoch)
             stream = train if (group is None or getattr(train, "rank_sharded", False)) else ddist.shard_batches(train, rank, world)
-            for i, batch, is_last in _with_last_flag(stream):
+            for i, batch, upcoming in _with_lookahead(stream):
+                is_last = upcoming is _END
                 # Lightning steps on every `accum`-th batch AND on the last batch of the epoch (a trailing partial
                 # group is not dropped); the divisor stays `accum` there as well
                 boundary = (i + 1) % self.accum == 0 or is_last
@@ -222,6 +227,8 @@ class Trainer:
                             torch._foreach_zero_(acc)
                 elif sync is not None:
                     loss = model.training_step(batch)          # this rank's SHARE of the global loss
+                    if prefetch is not None and not is_last:
+                        prefetch(upcoming)
                     if boundary:
                         with sync.hooks():                     # all-reduce launched from inside this backward
                             (loss / self.accum).backward()
@@ -231,6 +238,10 @@ class Trainer:
                     last = (loss.detach(), dict(getattr(model, "last_losses", {})))
                 else:
                     loss = model.training_step(batch)
+                    if prefetch is not None and not is_last:
+                        # the NEXT batch's frozen meta-teacher starts now, on its own stream, and runs beside this batch's
+                        # backward and the optimizer (CLIPImageDistillation.prefetch_teacher; tensor batches only)
+                        prefetch(upcoming)
                     (loss / self.accum).backward()
                     last = loss.detach()
                 if boundary:
