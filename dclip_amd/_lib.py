@@ -32,6 +32,8 @@ SIGNATURES = {
     "dclip_layernorm_bwd_ex": (I, [P, P, P, P, P, P, P, P, P, P, P, I, I, I, P, Z, P]),
     "dclip_attention_fwd": (I, [P, P, P, I, I, I, I, P]),
     "dclip_attention_bwd": (I, [P, P, P, P, P, P, I, I, I, I, P]),
+    "dclip_attention_bwd_workspace": (Z, [I, I, I, I]),
+    "dclip_attention_bwd_ws": (I, [P, P, P, P, P, P, Z, I, I, I, I, P]),
     "dclip_attention_cls_fwd": (I, [P, P, P, I, I, I, P]),
     "dclip_attention_cls_bwd": (I, [P, P, P, P, P, P, I, I, I, P]),
     "dclip_attention_row_fwd": (I, [P, P, P, P, I, I, I, P]),

@@ -1034,11 +1034,14 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_stream_kernel(AttnArgs a, con
 // dK, dV for 32 keys per wave: S = Q K^T and dP = dO V^T with lane = key column and the queries
 // {(r&3) + 8(r>>2) + 4 half} of a 32-query block in registers: P and dS are the B operands of dV^T = dO^T P and
 // dK^T = Q^T dS.  Q / dO tiles (64 queries) stream through LDS with their lse and delta.
-template <bool CAUSAL>
+// WRITE_DS: the dS block (formed here once) also goes to `ds` as dS^T [B*H][Sp keys][Sp queries] (Sp = S rounded up to 32;
+// masked entries are written as zeros) for attn_bwd_dq_from_ds_kernel, which then needs ONE product instead of three
+// (see the dS-passing note below).
+template <bool CAUSAL, bool WRITE_DS = false>
 __global__ void __launch_bounds__(256) attn_bwd_dkv_stream_kernel(AttnArgs a, const float* __restrict__ dout,
                                                                   const float* __restrict__ lse, const float* __restrict__ delta,
                                                                   float* __restrict__ dk_out, float* __restrict__ dv_out,
-                                                                  int lddkv) {
+                                                                  int lddkv, float* __restrict__ ds = nullptr, int Sp = 0) {
   __shared__ __attribute__((aligned(16))) float lds[2 * TS * HD + 2 * TS];
   float* Qs = lds;
   float* dOs = lds + TS * HD;
@@ -1114,6 +1117,12 @@ __global__ void __launch_bounds__(256) attn_bwd_dkv_stream_kernel(AttnArgs a, co
         pr[r] = masked ? 0.f : __expf(s2[r] * kScale - lse_s[ql]);
         s2[r] = pr[r] * (dp2[r] - dl_s[ql]) * kScale;   // dS
       }
+      if (WRITE_DS) {   // row = this lane's key (< Sp: the wave is live), 4 consecutive queries per 16-byte store
+        float* drow = ds + ((size_t)bh * Sp + key) * Sp + qt * TS + 32 * sub + 4 * half;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          *reinterpret_cast<f32x4*>(drow + 8 * j) = f32x4{s2[4 * j], s2[4 * j + 1], s2[4 * j + 2], s2[4 * j + 3]};
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int ql = 32 * sub + (r & 3) + 8 * (r >> 2) + 4 * half;
@@ -1134,6 +1143,102 @@ __global__ void __launch_bounds__(256) attn_bwd_dkv_stream_kernel(AttnArgs a, co
         *reinterpret_cast<f32x4*>(dk_out + o + 32 * dt + 8 * j) = f32x4{dk[dt][4 * j], dk[dt][4 * j + 1], dk[dt][4 * j + 2], dk[dt][4 * j + 3]};
         *reinterpret_cast<f32x4*>(dv_out + o + 32 * dt + 8 * j) = f32x4{dv[dt][4 * j], dv[dt][4 * j + 1], dv[dt][4 * j + 2], dv[dt][4 * j + 3]};
       }
+  }
+}
+
+// ------------------------------------------------------------------------------------------- backward, streamed, dS passed
+// The two-kernel split above forms S and dP twice (7 MFMA products for 5).  With dS passed through memory the dQ kernel
+// needs one product: delta first (a row-dot kernel), then attn_bwd_dkv_stream_kernel<.., true> forms S, P, dP, dS ONCE,
+// takes dV and dK from them and writes dS^T [B*H][Sp][Sp] (fp32, 308 MB at 128 x 197 tokens x 12 heads — 80 us of HBM time
+// against the ~330 us of matrix time the two dropped products took), and attn_bwd_dq_from_ds_kernel computes dQ = dS K.
+
+// delta[bh][q] = sum_d O[q][d] dO[q][d]: 16 lanes per (token, head), 16 pairs per workgroup
+__global__ void __launch_bounds__(256) attn_delta_kernel(const float* __restrict__ out, const float* __restrict__ dout,
+                                                         float* __restrict__ delta, int B, int S, int H) {
+  const long pair = (long)blockIdx.x * 16 + (threadIdx.x >> 4);
+  const int part = threadIdx.x & 15;
+  float s = 0.f;
+  const bool live = pair < (long)B * S * H;
+  const long token = live ? pair / H : 0;
+  const int h = live ? (int)(pair % H) : 0;
+  if (live) {
+    const size_t off = (size_t)token * H * HD + h * HD + 4 * part;
+    const f32x4 o4 = *reinterpret_cast<const f32x4*>(out + off);
+    const f32x4 d4 = *reinterpret_cast<const f32x4*>(dout + off);
+    s = (o4[0] * d4[0] + o4[1] * d4[1]) + (o4[2] * d4[2] + o4[3] * d4[3]);
+  }
+  s += __shfl_xor(s, 8);
+  s += __shfl_xor(s, 4);
+  s += __shfl_xor(s, 2);
+  s += __shfl_xor(s, 1);
+  if (live && part == 0) {
+    const long b = token / S, q = token % S;
+    delta[((size_t)b * H + h) * S + q] = s;
+  }
+}
+
+// dQ^T (64 x 32 queries per wave) = K^T dS^T with dS^T read back from memory: lane (l31, half) loads, for ITS query,
+// the keys {(r&3) + 8(r>>2) + 4 half} of a 32-key block — 128-byte runs along the query axis, already the B operand of
+// v_mfma_f32_32x32x2_f32 — one block ahead of the products.  The whole K of the head sits in LDS (64-row tiles: 64 KiB
+// at 197 tokens, 80 KiB at 257), staged once: no barrier in the loop.
+// Measured at 128 x 197 tokens x 12 heads (rocprofv3): 166 us — one product at the ~50 % matrix-pipe efficiency every
+// kernel of this family reaches (197 padded to 224 on both axes, one LDS read per MFMA), against 421 us for the kernel
+// that re-forms S and dP.  Forms that were slower: dS as [query][key] with 4-byte stores in the dK/dV kernel and a
+// per-wave LDS transposition here (149 us, but +80 us of stores there instead of +30); all of a wave's dS^T loads
+// requested up front (144-184 VGPRs: 195 us); K streamed through two tiles for four workgroups per CU (205 us).
+__global__ void __launch_bounds__(256) attn_bwd_dq_from_ds_kernel(AttnArgs a, const float* __restrict__ ds, int Sp,
+                                                                  float* __restrict__ dq_out, int lddq) {
+  extern __shared__ __attribute__((aligned(16))) float Kall[];      // [64 * tiles][64], swizzled per 64-row tile
+  const int H = a.H, S = a.Sk;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l31 = lane & 31, half = lane >> 5;
+  const int bh = blockIdx.x, b = bh / H, h = bh % H;
+  const int q0 = blockIdx.y * 128 + wave * 32;
+  const int query = q0 + l31;
+  const float* kbase = a.k + (size_t)b * S * a.ldkv + h * HD;
+  const int nkt = (S + TS - 1) / TS;
+  for (int kt = 0; kt < nkt; kt += 2) {                            // two tiles' loads in flight
+    f32x4 v0[4], v1[4];
+    tile_fetch(v0, kbase, kt * TS, S, (size_t)a.ldkv);
+    if (kt + 1 < nkt) tile_fetch(v1, kbase, (kt + 1) * TS, S, (size_t)a.ldkv);
+    tile_commit(Kall + (size_t)kt * TS * HD, v0, kt * TS, S);
+    if (kt + 1 < nkt) tile_commit(Kall + (size_t)(kt + 1) * TS * HD, v1, (kt + 1) * TS, S);
+  }
+  __syncthreads();
+  if (q0 >= S) return;                                             // (after the only barrier)
+  // dS^T rows of key block kb (32 keys) for this lane's query: element r at row 32 kb + (r&3) + 8(r>>2) + 4 half
+  const float* dcol = ds + (size_t)bh * Sp * Sp + query;           // query < Sp: the wave is live
+  const int nkb = (S + 31) / 32;
+  f32x16 cur, nxt;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) cur[r] = dcol[(size_t)((r & 3) + 8 * (r >> 2) + 4 * half) * Sp];
+  f32x16 dq[2];
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dq[dt][r] = 0.f;
+  for (int kb = 0; kb < nkb; ++kb) {
+    const int kn = min(kb + 1, nkb - 1);                           // (the last iteration re-reads its own block: unused)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) nxt[r] = dcol[(size_t)(32 * kn + (r & 3) + 8 * (r >> 2) + 4 * half) * Sp];
+    const float* Kt = Kall + (size_t)(kb >> 1) * TS * HD;
+    const int sub = kb & 1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = 32 * sub + (r & 3) + 8 * (r >> 2) + 4 * half;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+        dq[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(Kt[tile_off(key, 32 * dt + l31)], cur[r], dq[dt], 0, 0, 0);
+    }
+    cur = nxt;
+  }
+  if (query < S) {
+    float* o = dq_out + ((size_t)b * S + query) * lddq + h * HD + 4 * half;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        *reinterpret_cast<f32x4*>(o + 32 * dt + 8 * j) = f32x4{dq[dt][4 * j], dq[dt][4 * j + 1], dq[dt][4 * j + 2], dq[dt][4 * j + 3]};
   }
 }
 
@@ -1439,8 +1544,12 @@ int launch_fwd(const AttnArgs& a, float* out, float* lse, int B, int causal, hip
   return DCLIP_OK;
 }
 
+inline int ds_row_stride(int S) { return cdiv(S, 32) * 32; }
+// dS passing: long non-causal self-attention whose whole K fits the dQ kernel's LDS (512 tokens = 128 KiB)
+inline bool long_noncausal(int Sq, int Sk, int causal) { return Sq == Sk && Sk > 80 && Sk <= 512 && !causal; }
+
 int launch_bwd(const AttnArgs& a, const float* out, const float* dout, const float* lse, float* dq, int lddq, float* dk,
-               float* dv, int lddkv, float* delta, int B, int causal, hipStream_t st) {
+               float* dv, int lddkv, float* delta, int B, int causal, hipStream_t st, float* ds = nullptr) {
   dim3 gq(B * a.H, cdiv(a.Sq, TS)), gk(B * a.H, cdiv(a.Sk, TS)), block(256);
   if (a.Sq == a.Sk && a.Sk > TS && a.Sk <= 80 && lddq == lddkv && !getenv("DCLIP_ATTN_TILED")) {
     // 65..80 rows (the 77-token text tower when it trains): whole-row kernel, 5 waves.  Measured 214 us vs 362 us for
@@ -1469,8 +1578,23 @@ int launch_bwd(const AttnArgs& a, const float* out, const float* dout, const flo
     // (128 x 197 tokens, 12 heads) 1160 vs 1486 us, at L/14 1383 vs 1460 us; a causal 130-token case was slower
     // (196 vs 177 us), and no configuration has a causal sequence above 80 tokens, so causal stays on the tiled path.
     dim3 g2(B * a.H, cdiv(a.Sq, 128));
+    if (ds && long_noncausal(a.Sq, a.Sk, causal) && !getenv("DCLIP_ATTN_NO_DS")) {   // dS formed once and passed through memory: 5 products instead of 7
+      const int Sp = ds_row_stride(a.Sk);
+      hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)cdivz((size_t)B * a.Sq * a.H, 16)), block, 0, st, out, dout, delta, B, a.Sq, a.H);
+      hipLaunchKernelGGL((attn_bwd_dkv_stream_kernel<false, true>), g2, block, 0, st, a, dout, lse, delta, dk, dv, lddkv, ds, Sp);
+      const size_t klds = (size_t)cdiv(a.Sk, TS) * TS * HD * sizeof(float);
+      static bool big_lds_set = false;
+      if (klds > 64 * 1024 && !big_lds_set) {
+        DCLIP_REQUIRE(hipFuncSetAttribute((const void*)attn_bwd_dq_from_ds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          128 * 1024) == hipSuccess, "attention_bwd: cannot raise the dQ kernel's LDS limit");
+        big_lds_set = true;
+      }
+      hipLaunchKernelGGL(attn_bwd_dq_from_ds_kernel, g2, block, klds, st, a, (const float*)ds, Sp, dq, lddq);
+      DCLIP_CHECK_LAUNCH("attention_bwd.stream_ds");
+      return DCLIP_OK;
+    }
     hipLaunchKernelGGL((attn_bwd_dq_stream_kernel<false>), g2, block, 0, st, a, out, dout, lse, dq, lddq, delta);
-    hipLaunchKernelGGL((attn_bwd_dkv_stream_kernel<false>), g2, block, 0, st, a, dout, lse, delta, dk, dv, lddkv);
+    hipLaunchKernelGGL((attn_bwd_dkv_stream_kernel<false>), g2, block, 0, st, a, dout, lse, delta, dk, dv, lddkv, (float*)nullptr, 0);
     DCLIP_CHECK_LAUNCH("attention_bwd.stream");
     return DCLIP_OK;
   }
@@ -1503,6 +1627,32 @@ DCLIP_API int dclip_attention_bwd(const float* qkv, const float* out, const floa
   const int D = H * HD;
   AttnArgs a{qkv, qkv + D, qkv + 2 * D, 3 * D, 3 * D, S, S, H, nullptr};
   return launch_bwd(a, out, dout, lse, dqkv, 3 * D, dqkv + D, dqkv + 2 * D, 3 * D, delta, B, causal, (hipStream_t)stream);
+}
+
+// Workspace form: `workspace` holds delta [B*H*S] and, for long non-causal sequences (S > 80: ViT-B/16's 197 tokens,
+// ViT-L/14's 257), the dS^T blocks [B*H][Sp][Sp] (Sp = S rounded up to 32) that let the dQ kernel skip re-forming S and dP.
+DCLIP_API size_t dclip_attention_bwd_workspace(int B, int S, int H, int causal) {
+  size_t n = (size_t)B * H * S;
+  n = (n + 63) / 64 * 64;                                   // dS rows start 256-byte aligned
+  if (long_noncausal(S, S, causal)) n += (size_t)B * H * ds_row_stride(S) * ds_row_stride(S);
+  return n * sizeof(float);
+}
+
+DCLIP_API int dclip_attention_bwd_ws(const float* qkv, const float* out, const float* dout, const float* lse, float* dqkv,
+                                     void* workspace, size_t workspace_bytes, int B, int S, int H, int causal, void* stream) {
+  DCLIP_REQUIRE(qkv && out && dout && lse && dqkv && workspace, "attention_bwd_ws: null pointer");
+  DCLIP_REQUIRE(B > 0 && S > 0 && H > 0, "attention_bwd_ws: bad shape B=%d S=%d H=%d", B, S, H);
+  DCLIP_REQUIRE((uintptr_t)workspace % 16 == 0, "attention_bwd_ws: workspace must be 16-byte aligned");
+  if (workspace_bytes < dclip_attention_bwd_workspace(B, S, H, causal)) {
+    dclip_set_error("attention_bwd_ws: workspace too small (%zu < %zu)", workspace_bytes,
+                    dclip_attention_bwd_workspace(B, S, H, causal));
+    return DCLIP_EWORKSPACE;
+  }
+  const int D = H * HD;
+  float* delta = (float*)workspace;
+  float* ds = long_noncausal(S, S, causal) ? delta + ((size_t)B * H * S + 63) / 64 * 64 : nullptr;
+  AttnArgs a{qkv, qkv + D, qkv + 2 * D, 3 * D, 3 * D, S, S, H, nullptr};
+  return launch_bwd(a, out, dout, lse, dqkv, 3 * D, dqkv + D, dqkv + 2 * D, 3 * D, delta, B, causal, (hipStream_t)stream, ds);
 }
 
 // bf16 I/O forms for the bf16 training student (S <= 80 forward, S <= 64 backward: the 50-token ViT-B/32): qkv16 [B*S][3D],

@@ -232,9 +232,11 @@ def attention_bwd(qkv, out, dout, lse, B: int, S: int, H: int, causal: bool):
             or lse.numel() != B * H * S:
         raise ValueError("attention_bwd: shape mismatch")
     dqkv = torch.empty_like(qkv)
-    delta = torch.empty((B * H * S,), dtype=torch.float32, device=qkv.device)
-    _lib.check(lib.dclip_attention_bwd(qkv.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(),
-                                       dqkv.data_ptr(), delta.data_ptr(), B, S, H, int(causal), _stream()),
+    # delta, and for long non-causal sequences the dS blocks the dK/dV kernel hands to the dQ kernel (include/dclip_hip.h)
+    nbytes = int(lib.dclip_attention_bwd_workspace(B, S, H, int(causal)))
+    ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=qkv.device)
+    _lib.check(lib.dclip_attention_bwd_ws(qkv.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(),
+                                          dqkv.data_ptr(), ws.data_ptr(), nbytes, B, S, H, int(causal), _stream()),
                "attention_bwd")
     return dqkv
 

@@ -128,6 +128,15 @@ int dclip_attention_fwd(const float* qkv, float* out, float* lse, int B, int S, 
 int dclip_attention_bwd(const float* qkv, const float* out, const float* dout, const float* lse,
                         float* dqkv, float* delta /* scratch [B*H*S] */, int B, int S, int H, int causal,
                         void* stream);
+/* Workspace form of the backward (what dclip_amd.ops.attention_bwd calls).  `workspace` (16-byte aligned,
+ * >= dclip_attention_bwd_workspace bytes) holds delta and — for long non-causal sequences (S > 80: the 197 tokens of
+ * ViT-B/16, the 257 of ViT-L/14) — the dS^T blocks [B*H][Sp][Sp], Sp = S rounded up to 32 (S <= 512; longer sequences keep the two-kernel split): dS is formed ONCE in the dK/dV kernel
+ * and read back by the dQ kernel (5 MFMA products instead of the 7 of the two-kernel recompute split); results equal
+ * dclip_attention_bwd's up to the summation order of delta.  Same reference arithmetic: hf:modeling_clip.py eager
+ * attention backward (autograd of :333-349). */
+size_t dclip_attention_bwd_workspace(int B, int S, int H, int causal);
+int dclip_attention_bwd_ws(const float* qkv, const float* out, const float* dout, const float* lse, float* dqkv,
+                           void* workspace, size_t workspace_bytes, int B, int S, int H, int causal, void* stream);
 /* CLS-only form for the LAST vision layer: the model reads only row 0 of the final hidden state
  * (hf:modeling_clip.py:650), so that layer's attention output is needed for one query row per (image, head).
  * out [B, H*64], lse [B, H].  _bwd writes d k / d v for every row and d q for the CLS rows of dqkv [B*S, 3*H*64];

@@ -170,6 +170,37 @@ def test_attention_fwd_bwd(dev, B, S, H, causal):
     assert relerr(dqkv, qd.grad) < 5e-5
 
 
+@pytest.mark.parametrize("B,S,H", [(2, 197, 3), (1, 257, 2), (3, 81, 1), (2, 128, 2), (1, 224, 1), (2, 225, 1), (1, 300, 2), (1, 512, 1), (1, 520, 1)])
+def test_attention_bwd_long_ds_passing_vs_recompute(dev, monkeypatch, B, S, H):
+    """Long non-causal sequences: the default backward forms dS once in the dK/dV kernel and hands it to the dQ kernel
+    through the workspace; DCLIP_ATTN_NO_DS=1 keeps the two-kernel split that forms S and dP twice.  Both against fp64,
+    dK / dV bit-identical between them (the same kernel body), and the C ABI refuses a short workspace."""
+    from dclip_amd import ops, _lib
+    qkv = rnd((B * S, 3 * H * 64), 11, 1.5)
+    dout = rnd((B * S, H * 64), 12)
+    qd = qkv.double().requires_grad_(True)
+    (ref_attention(qd, B, S, H, False) * dout.double()).sum().backward()
+    out, lse = ops.attention_fwd(qkv.to(dev), B, S, H, False)
+    got = ops.attention_bwd(qkv.to(dev), out, dout.to(dev), lse, B, S, H, False)
+    monkeypatch.setenv("DCLIP_ATTN_NO_DS", "1")
+    old = ops.attention_bwd(qkv.to(dev), out, dout.to(dev), lse, B, S, H, False)
+    monkeypatch.delenv("DCLIP_ATTN_NO_DS")
+    assert relerr(got, qd.grad) < 5e-5 and relerr(old, qd.grad) < 5e-5
+    D = H * 64
+    assert relerr(got[:, :D], old[:, :D]) < 2e-5                     # dQ: another kernel, same arithmetic up to order
+    assert relerr(got[:, D:], old[:, D:]) < 2e-6                     # dK, dV: only delta's summation order differs
+    lib = _lib.load()
+    need = int(lib.dclip_attention_bwd_workspace(B, S, H, 0))
+    Sp = (S + 31) // 32 * 32
+    assert need >= 4 * (B * H * S + (B * H * Sp * Sp if S <= 512 else 0))    # longer: the two-kernel split, delta only
+    assert int(lib.dclip_attention_bwd_workspace(B, 50, H, 0)) == 4 * ((B * H * 50 + 63) // 64 * 64)      # short: delta only
+    ws = torch.empty(need // 4, dtype=torch.float32, device=dev)
+    dq = torch.empty_like(got)
+    rc = lib.dclip_attention_bwd_ws(qkv.to(dev).data_ptr(), out.data_ptr(), dout.to(dev).data_ptr(), lse.data_ptr(), dq.data_ptr(),
+                                    ws.data_ptr(), need - 4, B, S, H, 0, None)
+    assert rc != 0 and "workspace too small" in lib.dclip_last_error().decode()
+
+
 def test_attention_online_softmax_rescale(dev):
     """A spike in a late key tile forces the running-max rescale branch (S spans several tiles)."""
     from dclip_amd import ops
