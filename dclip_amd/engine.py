@@ -636,13 +636,34 @@ def layer_bwd_bf16(dx2, p: LayerParams, c: dict, pre: str, saved, B: int, S: int
     return dx, None, gr
 
 
+_PATCH_BF16_PLAN: Dict[tuple, bool] = {}
+
+
+def _patch_embed_bf16(v, rows: int) -> bool:
+    """Does the patch embedding of the TRAINING tower (the convolution as a GEMM: [rows = images x patches][3 p p] x
+    [D][3 p p]^T, and its weight gradient) run on the bf16 MFMAs like the encoder layers?  Yes when the one-pass bf16
+    im2col and the token-major weight-gradient kernel both apply to the shape (`DCLIP_BF16_PATCH=0`: keep it fp32, as
+    rounds 2-3 had it: 0.44 + 0.43 ms of fp32 GEMM per step at 256 images against 0.05 + 0.07)."""
+    key = (v.hidden_size, v.patch_dim, v.patch_size, rows)
+    hit = _PATCH_BF16_PLAN.get(key)
+    if hit is None:
+        hit = (os.environ.get("DCLIP_BF16_PATCH", "1") != "0" and v.patch_size % 4 == 0 and v.patch_dim % 64 == 0
+               and _lib.load().dclip_gemm_bf16_wgrad_tokmajor_plan(v.hidden_size, v.patch_dim, rows) > 0)
+        _PATCH_BF16_PLAN[key] = hit
+    return hit
+
+
 def vision_fwd_bf16_train(p: VisionParams, pixel_values: torch.Tensor, cfg, cache: dict):
-    """get_image_features with gradients, bf16 GEMM inputs in the encoder layers."""
+    """get_image_features with gradients, bf16 GEMM inputs in the patch embedding and the encoder layers."""
     v = cfg
     B = pixel_values.shape[0]
     S, D, H = v.seq_len, v.hidden_size, v.num_attention_heads
-    cols = ops.im2col(pixel_values, v.patch_size)
-    patch = ops.gemm(cols, p.patch_w.view(D, -1), ops.LAYOUT_NT)
+    if _patch_embed_bf16(v, B * (S - 1)):
+        cols = ops.im2col_bf16(pixel_values, v.patch_size)                    # one pass: gather + round; kept for the wgrad
+        patch = ops.gemm_bf16(cols, _w16(cache, "vpatch", p.patch_w), k=v.patch_dim)
+    else:
+        cols = ops.im2col(pixel_values, v.patch_size)
+        patch = ops.gemm(cols, p.patch_w.view(D, -1), ops.LAYOUT_NT)
     emb = ops.vision_assemble_fwd(patch, p.class_embedding, p.pos, B, S, D)
     del patch
     x, m0, r0 = ops.layernorm_fwd(emb, p.pre_w, p.pre_b, v.layer_norm_eps, save_stats=True)
@@ -714,7 +735,13 @@ def vision_bwd_bf16(p: VisionParams, saved, d_out: torch.Tensor, cfg, need: List
         if needd["patch_w"]:
             dpatch = ops.vision_assemble_bwd(demb, B, S, D)
             pw = _galloc(alloc, "patch_w", (D, p.patch_w.numel() // D), dev)
-            grads["patch_w"] = ops.gemm(dpatch, cols, ops.LAYOUT_TN, out=pw).view_as(p.patch_w)
+            if cols.dtype == torch.bfloat16:          # token-major split-K weight gradient from the saved bf16 columns
+                got = ops.gemm_bf16_wgrad_tokmajor(ops.cast_bf16(dpatch), cols, out=pw)
+                if got is None:
+                    raise RuntimeError("patch-embedding weight gradient: the token-major bf16 kernel refused a shape its plan accepted")
+                grads["patch_w"] = got.view_as(p.patch_w)
+            else:
+                grads["patch_w"] = ops.gemm(dpatch, cols, ops.LAYOUT_TN, out=pw).view_as(p.patch_w)
         if on_ready is not None:
             on_ready({n: grads[n] for n in VisionParams.HEAD if grads[n] is not None})
     return [grads[n] for n in names]

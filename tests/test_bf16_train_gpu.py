@@ -382,3 +382,42 @@ def test_attention_bf16_mfma_training_pair(B, S, H, causal):
         d2 = ops.attention_bwd_io16(qkv16, o2, dout16, l2, B, S, H, causal).float()[:, 2 * D:].reshape(-1)      # dv (never zero)
         a = dq16.float()[:, 2 * D:].reshape(-1)
         assert float(a @ d2 / (a.norm() * d2.norm())) > 0.9998
+
+
+def test_bf16_patch_embedding_runs_on_the_bf16_mfmas(monkeypatch):
+    """The bf16 student's patch embedding (convolution as a GEMM) and its weight gradient on the bf16 kernels (default at
+    the benched shape) against the same step with that one GEMM pair in fp32 (DCLIP_BF16_PATCH=0), and against the all-fp32
+    step: the loss moves by < 5e-4, no gradient tensor turns (the gates of test_bf16_training_step_against_fp32 hold for
+    both)."""
+    from dclip_amd import engine
+    from dclip_amd.clip_model import from_hf_state_dict
+    dev = torch.device("cuda:0")
+    cfg = dcfg.vit_b32()
+    B = 256
+    m = from_hf_state_dict(cfg, synth.synth_clip_state_dict(cfg, seed=0, gain=3.0), device=dev)
+    for p in m.text_model.parameters():
+        p.requires_grad = False
+    m.text_projection.weight.requires_grad = False
+    m.logit_scale.requires_grad = False
+    pix = synth.synth_pixel_values(B, cfg.vision, seed=0).to(dev)
+    ids = synth.synth_input_ids(B, cfg.text, seed=3, ragged=True).to(dev)
+    t_img = synth.synth_embeddings(B, cfg.projection_dim, seed=1).to(dev)
+    l32, e32, g32 = _step(m, pix, ids, t_img, "fp32")
+    monkeypatch.setenv("DCLIP_BF16_PATCH", "0")
+    engine._PATCH_BF16_PLAN.clear()
+    l_off, e_off, g_off = _step(m, pix, ids, t_img, "bf16")
+    assert list(engine._PATCH_BF16_PLAN.values()) == [False]
+    monkeypatch.delenv("DCLIP_BF16_PATCH")
+    engine._PATCH_BF16_PLAN.clear()
+    l_on, e_on, g_on = _step(m, pix, ids, t_img, "bf16")
+    assert list(engine._PATCH_BF16_PLAN.values()) == [True]                 # 12,544 patch rows: the bf16 path is the default
+    key = "vision_model.embeddings.patch_embedding.weight"
+    cos = lambda a, b: float(a @ b / (a.norm() * b.norm()).clamp_min(1e-30))
+    c_on = {k: cos(g_on[k], g32[k]) for k in g32}
+    c_off = {k: cos(g_off[k], g32[k]) for k in g32}
+    print(f"patch embedding bf16: loss fp32 {l32:.6f} | bf16 layers only {l_off:.6f} | + bf16 patch GEMMs {l_on:.6f}; patch-weight "
+          f"gradient cosine vs fp32 {c_off[key]:.6f} -> {c_on[key]:.6f}; min over tensors {min(c_off.values()):.5f} -> {min(c_on.values()):.5f}; "
+          f"embedding min cos {float(torch.nn.functional.cosine_similarity(e_on, e32, dim=1).min()):.6f}")
+    assert abs(l_on - l_off) <= 5e-4 * abs(l32) and abs(l_on - l32) <= 2e-3 * abs(l32)
+    assert c_on[key] > 0.999 and min(c_on.values()) > 0.98
+    assert float(torch.nn.functional.cosine_similarity(e_on, e32, dim=1).min()) > 0.999
