@@ -37,6 +37,7 @@ SIGNATURES = {
     "dclip_attention_cls_fwd": (I, [P, P, P, I, I, I, P]),
     "dclip_attention_cls_bwd": (I, [P, P, P, P, P, P, I, I, I, P]),
     "dclip_attention_row_fwd": (I, [P, P, P, P, I, I, I, P]),
+    "dclip_attention_row_fwd_bf16": (I, [P, P, P, I, I, I, P]),
     "dclip_im2col_bf16": (I, [P, P, I, I, I, I, I, I, P]),
     "dclip_im2col": (I, [P, P, I, I, I, I, I, P]),
     "dclip_vision_assemble_fwd": (I, [P, P, P, P, I, I, I, P]),

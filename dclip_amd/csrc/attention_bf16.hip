@@ -630,7 +630,105 @@ __global__ void __launch_bounds__(128) attn_bwd_bf16_kernel(const unsigned short
   }
 }
 
+
+// ------------------------------------------------------------------------------------------- one query row per (sequence, head)
+// The LAST layer of a frozen tower is needed for one row only: the CLS row of every image (hf:modeling_clip.py:650) or the
+// first-EOS row of every caption (:574-581; causal: keys 0..row).  One WAVE per (sequence, head): lane j scores keys
+// j, j + 64, ... against the query (128-byte key rows, the query row broadcast), the softmax runs across the wave, then
+// lane d accumulates head dimension d of sum_j p_j V[j] (128-byte coalesced V rows, p_j by a wave shuffle).  Bound by
+// reading K and V once: 2 x 2 B x S x 64 per (sequence, head) — the generic fp32 kernel it replaces here padded the one
+// query row to a 64-row tile (390 us at 2048 crops x 12 heads x 50 tokens, against ~60 us of bytes).
+constexpr int ROW_MAXI = 8;        // keys per lane: S <= 512
+__global__ void __launch_bounds__(256) attn_row_fwd_bf16_kernel(const unsigned short* __restrict__ qkv, const int* __restrict__ rows,
+                                                                unsigned short* __restrict__ out, int B, int S, int H) {
+  const int lane = threadIdx.x & 63;
+  const int bh = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (bh >= B * H) return;
+  const int b = bh / H, h = bh % H;
+  const int D = H * HD, ld = 3 * D;
+  const int qrow = rows ? min(max(rows[b], 0), S - 1) : 0;
+  const int nkeys = rows ? qrow + 1 : S;
+  const unsigned short* base = qkv + (size_t)b * S * ld + h * HD;
+  float q[64];
+  {
+    const unsigned short* qp = base + (size_t)qrow * ld;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const u32x4 w = *reinterpret_cast<const u32x4*>(qp + 8 * c);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        q[8 * c + 2 * e] = __builtin_bit_cast(float, w[e] << 16);
+        q[8 * c + 2 * e + 1] = __builtin_bit_cast(float, w[e] & 0xffff0000u);
+      }
+    }
+  }
+  float sc[ROW_MAXI];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < ROW_MAXI; ++i) {
+    const int j = lane + 64 * i;
+    sc[i] = -INFINITY;
+    if (64 * i < nkeys) {                                     // wave-uniform
+      const unsigned short* kp = base + D + (size_t)min(j, nkeys - 1) * ld;
+      float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const u32x4 w = *reinterpret_cast<const u32x4*>(kp + 8 * c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          a0 += q[8 * c + 2 * e] * __builtin_bit_cast(float, w[e] << 16);
+          a1 += q[8 * c + 2 * e + 1] * __builtin_bit_cast(float, w[e] & 0xffff0000u);
+        }
+      }
+      if (j < nkeys) sc[i] = (a0 + a1) * kScale;
+      mx = fmaxf(mx, sc[i]);
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < ROW_MAXI; ++i) {
+    sc[i] = (64 * i < nkeys && lane + 64 * i < nkeys) ? __expf(sc[i] - mx) : 0.f;
+    sum += sc[i];
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+  const float inv = 1.f / sum;
+  // lane d: out[d] = sum_j p_j V[j][d]
+  const unsigned short* vp = base + 2 * D + lane;
+  float acc0 = 0.f, acc1 = 0.f;
+#pragma unroll
+  for (int i = 0; i < ROW_MAXI; ++i) {
+    if (64 * i >= nkeys) break;                               // wave-uniform
+    const int n = min(64, nkeys - 64 * i);
+    int jj = 0;
+    for (; jj + 1 < n; jj += 2) {
+      const float p0 = __shfl(sc[i], jj), p1 = __shfl(sc[i], jj + 1);
+      const float v0 = __builtin_bit_cast(float, (unsigned int)vp[(size_t)(64 * i + jj) * ld] << 16);
+      const float v1 = __builtin_bit_cast(float, (unsigned int)vp[(size_t)(64 * i + jj + 1) * ld] << 16);
+      acc0 += p0 * v0;
+      acc1 += p1 * v1;
+    }
+    if (jj < n) acc0 += __shfl(sc[i], jj) * __builtin_bit_cast(float, (unsigned int)vp[(size_t)(64 * i + jj) * ld] << 16);
+  }
+  out[(size_t)b * D + h * HD + lane] = bf16_bits((acc0 + acc1) * inv);
+}
+
 }  // namespace
+
+// One attention output row per sequence, bf16 in / bf16 out (the LAST layer of a frozen bf16 tower): rows == NULL: query row 0
+// against all S keys (the CLS row of a vision tower); rows [B] int32: query row rows[b] against keys 0..rows[b] (the first-EOS
+// row of a causal text tower).  qkv [B*S][3*H*64] bf16, out [B][H*64] bf16.  S <= 512.
+DCLIP_API int dclip_attention_row_fwd_bf16(const void* qkv, const int32_t* rows, void* out, int B, int S, int H, void* stream) {
+  DCLIP_REQUIRE(qkv && out, "attention_row_fwd_bf16: null pointer");
+  DCLIP_REQUIRE(B > 0 && S > 0 && S <= 64 * ROW_MAXI && H > 0, "attention_row_fwd_bf16: B=%d S=%d (<= 512) H=%d", B, S, H);
+  DCLIP_REQUIRE((uintptr_t)qkv % 16 == 0, "attention_row_fwd_bf16: 16-byte alignment");
+  hipLaunchKernelGGL(attn_row_fwd_bf16_kernel, dim3(cdiv(B * H, 4)), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)qkv,
+                     (const int*)rows, (unsigned short*)out, B, S, H);
+  DCLIP_CHECK_LAUNCH("attention_row_fwd_bf16");
+  return DCLIP_OK;
+}
 
 // Training forms (bf16 student, configs c3 / c5): the forward also leaves the log-sum-exp of the scaled scores (S <= 288,
 // the whole-head kernel), the backward (S <= 64) returns dq | dk | dv as bf16 [B*S][3*H*64].

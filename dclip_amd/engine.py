@@ -336,9 +336,14 @@ def vision_fwd_bf16(p: VisionParams, pixel_values: torch.Tensor, cfg, cache: dic
     lp, pre = p.layers[-1], f"v{len(p.layers) - 1}."
     # last layer on the CLS rows only (see last_layer_fwd_cls)
     ln1 = ops.layernorm_fwd_bf16(x, lp.ln1_w, lp.ln1_b, v.layer_norm_eps)
-    qkv = ops.gemm_bf16(ln1, _w16(cache, pre + "qkv", lp.qkv_w), bias=lp.qkv_b)
-    attn, _ = ops.attention_cls_fwd(qkv, B, S, H)
-    x1 = ops.gemm_bf16(ops.cast_bf16(attn), _w16(cache, pre + "out", lp.out_w), bias=lp.out_b,
+    if S <= 512 and os.environ.get("DCLIP_BF16_ROW_ATTN", "1") != "0":
+        # q | k | v written as bf16 (half the bytes of the 2304-wide projection's output), one-row kernel on them
+        qkv = ops.gemm_bf16(ln1, _w16(cache, pre + "qkv", lp.qkv_w), bias=lp.qkv_b, out_bf16=True)
+        attn16 = ops.attention_row_fwd_bf16(qkv, None, B, S, H)
+    else:
+        qkv = ops.gemm_bf16(ln1, _w16(cache, pre + "qkv", lp.qkv_w), bias=lp.qkv_b)
+        attn16 = ops.cast_bf16(ops.attention_cls_fwd(qkv, B, S, H)[0])
+    x1 = ops.gemm_bf16(attn16, _w16(cache, pre + "out", lp.out_w), bias=lp.out_b,
                        residual=ops.gather_rows(x, None, B, S, D))
     ln2 = ops.layernorm_fwd_bf16(x1, lp.ln2_w, lp.ln2_b, v.layer_norm_eps)
     g = ops.gemm_bf16(ln2, _w16(cache, pre + "fc1", lp.fc1_w), bias=lp.fc1_b, gelu=True, out_bf16=True)
@@ -893,9 +898,13 @@ def text_fwd_frozen_bf16(p: TextParams, input_ids: torch.Tensor, cfg, cache: dic
     x = _text_stack_bf16(p, input_ids, cfg, cache, len(p.layers) - 1)
     lp, pre = p.layers[-1], f"t{len(p.layers) - 1}."
     ln1 = ops.layernorm_fwd_bf16(x, lp.ln1_w, lp.ln1_b, t.layer_norm_eps)
-    qkv = ops.gemm_bf16(ln1, _w16(cache, pre + "qkv", lp.qkv_w), bias=lp.qkv_b)
-    attn = ops.attention_row_fwd(qkv, eos, B, T, H)
-    x1 = ops.gemm_bf16(ops.cast_bf16(attn), _w16(cache, pre + "out", lp.out_w), bias=lp.out_b,
+    if T <= 512 and os.environ.get("DCLIP_BF16_ROW_ATTN", "1") != "0":
+        qkv = ops.gemm_bf16(ln1, _w16(cache, pre + "qkv", lp.qkv_w), bias=lp.qkv_b, out_bf16=True)
+        attn16 = ops.attention_row_fwd_bf16(qkv, eos, B, T, H)
+    else:
+        qkv = ops.gemm_bf16(ln1, _w16(cache, pre + "qkv", lp.qkv_w), bias=lp.qkv_b)
+        attn16 = ops.cast_bf16(ops.attention_row_fwd(qkv, eos, B, T, H))
+    x1 = ops.gemm_bf16(attn16, _w16(cache, pre + "out", lp.out_w), bias=lp.out_b,
                        residual=ops.gather_rows(x, eos, B, T, D))
     ln2 = ops.layernorm_fwd_bf16(x1, lp.ln2_w, lp.ln2_b, t.layer_norm_eps)
     g = ops.gemm_bf16(ln2, _w16(cache, pre + "fc1", lp.fc1_w), bias=lp.fc1_b, gelu=True, out_bf16=True)

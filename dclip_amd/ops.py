@@ -766,6 +766,22 @@ def attention_bwd_bf16(qkv, out, dout, lse, B: int, S: int, H: int, causal: bool
     return dqkv
 
 
+def attention_row_fwd_bf16(qkv: torch.Tensor, rows: Optional[torch.Tensor], B: int, S: int, H: int) -> torch.Tensor:
+    """One attention output row per sequence from a bf16 qkv [B*S, 3*H*64]: row 0 against all keys (rows None: the CLS row of a
+    vision tower's last layer) or row rows[b] against keys 0..rows[b] (int32 [B]: the first-EOS row of the causal text tower).
+    Returns [B, H*64] bf16."""
+    lib = _lib.load()
+    _bf16(qkv, "qkv")
+    if tuple(qkv.shape) != (B * S, 3 * H * 64):
+        raise ValueError(f"attention_row_fwd_bf16: qkv shape {tuple(qkv.shape)} != {(B * S, 3 * H * 64)}")
+    if rows is not None and not (rows.is_cuda and rows.dtype == torch.int32 and rows.numel() == B and rows.is_contiguous()):
+        raise ValueError("attention_row_fwd_bf16: rows must be a contiguous int32 CUDA tensor [B]")
+    out = torch.empty((B, H * 64), dtype=torch.bfloat16, device=qkv.device)
+    _lib.check(lib.dclip_attention_row_fwd_bf16(qkv.data_ptr(), None if rows is None else rows.data_ptr(), out.data_ptr(),
+                                                B, S, H, _stream()), "attention_row_fwd_bf16")
+    return out
+
+
 def attention_fwd_io16(qkv: torch.Tensor, B: int, S: int, H: int, causal: bool):
     """Short sequences (S <= 80), bf16 in / bf16 out, fp32 arithmetic: qkv [B*S, 3*H*64] bf16 -> (context bf16, lse fp32)."""
     lib = _lib.load()

@@ -355,6 +355,11 @@ int dclip_colsum_bf16(const void* X, float* out, int M, int N, int ldx, int accu
 /* Softmax attention of the frozen towers on bf16 q/k/v (the fused projection [B*S, 3*H*64] as written by
  * dclip_gemm_bf16 with out_bf16): fp32 scores / softmax, bf16 P and context [B*S, H*64].  Forward only. */
 int dclip_attention_fwd_bf16(const void* qkv, void* out, int B, int S, int H, int causal, void* stream);
+/* One attention output row per sequence for the LAST layer of a frozen bf16 tower: rows == NULL -> query row 0 against all
+ * S keys (only the CLS row of the final hidden state is read, hf:modeling_clip.py:650); rows [B] int32 -> query row rows[b]
+ * against keys 0..rows[b] (the pooled first-EOS row of the causal text tower, hf:modeling_clip.py:574-581).
+ * qkv [B*S, 3*H*64] bf16, out [B, H*64] bf16, S <= 512; fp32 scores / softmax / accumulation. */
+int dclip_attention_row_fwd_bf16(const void* qkv, const int32_t* rows, void* out, int B, int S, int H, void* stream);
 /* Training forms of the bf16 attention (the bf16 student of configs c3 / c5; eager_attention_forward, hf:modeling_clip.py:259-277,
  * and its gradient): bf16 q/k/v, context, d(context) and dq|dk|dv; fp32 scores, softmax and dS; P and dS rounded to bf16 for
  * the products they feed.  The forward (S <= 288, not 257) also writes lse [B*H][S] fp32 = log-sum-exp of the scaled scores;

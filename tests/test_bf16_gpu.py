@@ -258,3 +258,35 @@ def test_persistent_pingpong_gemm_against_the_one_tile_kernel(M, N, K, monkeypat
         assert float((per[3] - one[3]).abs().max()) <= 2e-6 * float(one[3].abs().max())
     assert float((per[0].double().cpu() - want).abs().max() / want.abs().max()) < 2e-6 * max(1.0, K ** 0.5)
     assert float((per[3].double().cpu() - (want + res.double().cpu())).abs().max() / want.abs().max()) < 1e-5
+
+
+@pytest.mark.parametrize("B,S,H,use_rows", [(3, 50, 12, False), (2, 257, 16, False), (5, 77, 8, True), (2, 1, 1, False),
+                                            (2, 300, 2, True), (1, 512, 1, False), (7, 197, 3, False), (4, 77, 12, True)])
+def test_attention_row_fwd_bf16(B, S, H, use_rows):
+    """The last layer's one-row attention of a frozen bf16 tower (CLS row against all keys; first-EOS row against keys
+    0..row) against fp64 on the same bf16-rounded q | k | v, and against the fp32 one-row kernels it replaces there."""
+    from dclip_amd import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(S * 31 + H)
+    qkv = (torch.randn(B * S, 3 * H * 64, generator=g) * 1.5).to(torch.bfloat16)
+    rows = torch.randint(0, S, (B,), generator=g, dtype=torch.int32) if use_rows else None
+    if use_rows:
+        rows[0] = S - 1
+        rows[-1] = 0
+    x = qkv.double().view(B, S, 3, H, 64)
+    want = torch.empty(B, H * 64, dtype=torch.float64)
+    for b in range(B):
+        r = int(rows[b]) if use_rows else 0
+        n = r + 1 if use_rows else S
+        q, k, v = x[b, r, 0], x[b, :n, 1], x[b, :n, 2]                # [H,64], [n,H,64]
+        p = torch.softmax(torch.einsum("hd,nhd->hn", q, k) * 0.125, dim=-1)
+        want[b] = torch.einsum("hn,nhd->hd", p, v).reshape(-1)
+    got = ops.attention_row_fwd_bf16(qkv.to(dev), None if rows is None else rows.to(dev), B, S, H)
+    assert got.dtype == torch.bfloat16 and tuple(got.shape) == (B, H * 64)
+    err = float((got.double().cpu() - want).abs().max() / want.abs().max())
+    assert err < 6e-3, err                                            # the bf16 rounding of the output
+    q32 = qkv.float().to(dev)
+    old = ops.attention_row_fwd(q32, rows.to(dev), B, S, H) if use_rows else ops.attention_cls_fwd(q32, B, S, H)[0]
+    assert float((got.float() - old).abs().max() / old.abs().max()) < 6e-3
+    with pytest.raises(ValueError):
+        ops.attention_row_fwd_bf16(qkv.to(dev)[:, :-64], None, B, S, H)
