@@ -77,14 +77,16 @@ class single_stream:
 
     def __enter__(self):
         if self.on:
-            self.prev = (self.module.overlap_teacher, os.environ.get("DCLIP_BF16_WGRAD_STREAM"))
+            self.prev = (self.module.overlap_teacher, os.environ.get("DCLIP_BF16_WGRAD_STREAM"), self.module.overlap_frozen_text)
             self.module.overlap_teacher = False
+            self.module.overlap_frozen_text = False
             os.environ["DCLIP_BF16_WGRAD_STREAM"] = "0"
         return self
 
     def __exit__(self, *exc):
         if self.on:
             self.module.overlap_teacher = self.prev[0]
+            self.module.overlap_frozen_text = self.prev[2]
             if self.prev[1] is None:
                 os.environ.pop("DCLIP_BF16_WGRAD_STREAM", None)
             else:
@@ -282,6 +284,8 @@ def extra_config(dev, timer, which: str, steps: int, warmup: int):
         B, spec, dtype = 128, ("c2", "ViT-B/16", None, 128, R, "fp32", "fp32"), "f32"
         what = "BASELINE config c4, one GPU's share (128 of the 1024 global pairs): ViT-B/16 distill step, fp32, bs=128"
     module, cfg, tcfg, batch = build_workload(*spec, dev, None, 0, fast_teacher_init=True)
+    # (as in the main loop: the frozen text tower beside the vision forward, except in the event-bracketed steps)
+    module.overlap_frozen_text = not os.environ.get("DCLIP_NO_TEXT_OVERLAP") and os.environ.get("DCLIP_EAGER_TEXT_OVERLAP", "1") != "0"
     T = cfg.text.max_position_embeddings
     trainable = [p for p in module.parameters() if p.requires_grad]
     opt = optim.FusedAdamW(trainable, lr=1e-6, max_grad_norm=0.5)
@@ -492,9 +496,16 @@ def main():
     # Default execution at N = 1 (c2): HIP-graph replay of forward + backward, with every `stride`-th step of the timed
     # region launched eagerly so that the GEMM launches of that step can be bracketed by HIP events.
     hybrid = None
-    exec_note = "eager launches"
+    # the frozen text tower's forward on a second stream beside the vision forward: inside the replayed graph always; in
+    # eagerly launched steps (N > 1, --eager, the meta-teacher workloads) too unless DCLIP_EAGER_TEXT_OVERLAP=0; never in
+    # the event-sampled steps (single_stream)
+    text_overlap = not os.environ.get("DCLIP_NO_TEXT_OVERLAP")
+    eager_text_overlap = os.environ.get("DCLIP_EAGER_TEXT_OVERLAP", "1") != "0"
+    module.overlap_frozen_text = text_overlap and eager_text_overlap
+    exec_note = "eager launches" + ("; the frozen text tower's forward on a second stream beside the vision forward (not in the "
+                                    "event-sampled steps)" if module.overlap_frozen_text else "")
     if meta:
-        exec_note = ("eager launches; the meta-teacher on a second stream — step n+1's teacher is started after step n's forward and "
+        exec_note = ("eager launches; the frozen student text tower and the meta-teacher on second streams — step n+1's teacher is started after step n's forward and "
                      "runs beside its backward, optimizer and the next student forward (one teacher pass per step; a step next "
                      "to an event-sampled one runs its teacher in the step, beside the student's image forward)"
                      + (", the bf16 weight-gradient GEMMs beside the data-gradient chain" if args.student_precision == "bf16" else "")
@@ -506,11 +517,11 @@ def main():
                 p_.grad = None
             # inside the replayed graph the frozen text tower's forward runs on a second stream beside the vision forward;
             # the eager (sampled, event-bracketed) steps launch every kernel alone on one stream
-            module.overlap_frozen_text = not os.environ.get("DCLIP_NO_TEXT_OVERLAP")
+            module.overlap_frozen_text = text_overlap
             try:
                 hybrid = GraphedStep(module, batch)
             finally:
-                module.overlap_frozen_text = False
+                module.overlap_frozen_text = text_overlap and eager_text_overlap
             hybrid_grads = [(p_, p_.grad) for p_ in trainable if p_.grad is not None]     # the graph's static gradients
             exec_note = ("HIP-graph replay of forward+backward (frozen text forward on a second stream beside the vision forward); "
                          "sampled steps launched eagerly, one stream, per-launch GEMM events")
