@@ -400,9 +400,13 @@ def main():
                     help="skip the untimed-by-the-contract extra measurements after the timed region (forward+backward "
                          "without the optimizer; HIP-graph replay)")
     ap.add_argument("--eager", action="store_true",
-                    help="launch every step kernel by kernel.  Default at N=1 on the benched workload: forward+backward are "
-                         "replayed from a captured HIP graph (bit-identical to the eager step, dclip_amd/graph.py) and every "
-                         "5th step of the timed region runs eagerly with HIP events around each GEMM launch")
+                    help="launch every step kernel by kernel — the default since round 3 (kept as a flag for scripts that pass it)")
+    ap.add_argument("--hybrid-graph", action="store_true",
+                    help="N=1, benched workload: forward+backward replayed from a captured HIP graph (bit-identical to the eager "
+                         "step, dclip_amd/graph.py), every 5th step of the timed region launched eagerly with HIP events around "
+                         "each GEMM launch.  The default of rounds 1-2; with the frozen text tower on its second stream in eager "
+                         "steps too, the eager loop measures the same (62.22 vs 62.31 ms without events) or faster (64.5 vs 65.3 "
+                         "with the sampled event steps) on the same box, so it is the default now")
     ap.add_argument("--graph", action="store_true",
                     help="replay forward+backward from a captured HIP graph (dclip_amd/graph.py; N=1 only).  Per-launch "
                          "GEMM events do not exist inside a graph: `roofline` is then taken from an eager pass of the "
@@ -493,8 +497,9 @@ def main():
             p_.grad = None
         graphed = GraphedStep(module, batch)
 
-    # Default execution at N = 1 (c2): HIP-graph replay of forward + backward, with every `stride`-th step of the timed
-    # region launched eagerly so that the GEMM launches of that step can be bracketed by HIP events.
+    # --hybrid-graph (N = 1, c2; the default of rounds 1-2): HIP-graph replay of forward + backward, with every `stride`-th step
+    # of the timed region launched eagerly so that the GEMM launches of that step can be bracketed by HIP events.  Default:
+    # every step launched eagerly (the host issues a step's ~430 launches in a fraction of its 62 ms).
     hybrid = None
     # the frozen text tower's forward on a second stream beside the vision forward: inside the replayed graph always; in
     # eagerly launched steps (N > 1, --eager, the meta-teacher workloads) too unless DCLIP_EAGER_TEXT_OVERLAP=0; never in
@@ -510,7 +515,7 @@ def main():
                      "to an event-sampled one runs its teacher in the step, beside the student's image forward)"
                      + (", the bf16 weight-gradient GEMMs beside the data-gradient chain" if args.student_precision == "bf16" else "")
                      + "; the steps sampled for per-launch GEMM events launch every kernel alone on one stream")
-    if graphed is None and world == 1 and not meta and not args.eager and opt is not None:
+    if graphed is None and world == 1 and not meta and args.hybrid_graph and not args.eager and opt is not None:
         try:
             from dclip_amd.graph import GraphedStep
             for p_ in trainable:
