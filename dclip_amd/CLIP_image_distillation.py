@@ -83,9 +83,10 @@ class CLIPImageDistillation(LightningLikeModule):
         self.student_precision = student_precision
         # Run the FROZEN text tower's forward on a second HIP stream beside the vision tower's forward (they share nothing
         # until the loss): the two GEMM chains fill each other's tile-round tails and per-workgroup prologue / epilogue gaps.
-        # Off by default — per-kernel timings (bench.py's GEMM events, rocprof) are only meaningful for kernels that run
-        # alone; bench.py switches it on for the captured HIP graph it replays.
-        self.overlap_frozen_text = False
+        # None = on unless DCLIP_TEXT_STREAM=0 (eager loop 63.1 -> 62.2 ms at the benched size, capturable in a HIP graph).
+        # Per-kernel timings (bench.py's GEMM events, rocprof) are only meaningful for kernels that run alone: bench.py sets
+        # it False for its event-bracketed steps.
+        self.overlap_frozen_text = None
         self._text_stream = None
         # Run the meta-teacher (tensor batches with `regions`) on a second HIP stream beside the student's image forward: the
         # two are independent until the loss, the bf16 student's GEMMs have 150 tiles for 256 CUs (one 128-KiB workgroup per
@@ -320,7 +321,11 @@ class CLIPImageDistillation(LightningLikeModule):
             and not self.student.text_projection.weight.requires_grad
         text_precision = "bf16" if (self.student_precision == "bf16" and text_frozen) else "fp32"
         text_job = None
-        if shared_sentence is None and text_frozen and self.overlap_frozen_text and tokens.is_cuda:
+        text_beside = self.overlap_frozen_text
+        if text_beside is None:
+            import os
+            text_beside = os.environ.get("DCLIP_TEXT_STREAM") != "0"
+        if shared_sentence is None and text_frozen and text_beside and tokens.is_cuda:
             main = torch.cuda.current_stream(dev)
             if self._text_stream is None:
                 self._text_stream = torch.cuda.Stream(device=dev)
