@@ -96,7 +96,7 @@ def test_two_rank_trainer_fit_equals_single_process(tmp_path, precision):
         # near-zero gradient elements shows up as a fraction of lr on those elements.  fp32: summation order only (1e-7
         # relative) — every element within 2 % of the total update.  bf16: a 1e-7 difference upstream flips the bf16 rounding
         # of ~1e-5 of the activation-gradient elements by 0.4 % each, which turns the sign of a few near-zero weight-gradient
-        # elements: bounded in NUMBER (< 0.1 % of the elements off by more than 2 % of the update) and in ENERGY (relative
+        # elements: bounded in NUMBER (< 0.5 % of the elements off by more than 2 % of the update) and in ENERGY (relative
         # L2 error of the whole update < 5 %); a missing rank or a wrong accumulation would move every element.
         d_ref = torch.cat([(want[n] - start[n]).reshape(-1) for n in want])
         d_got = torch.cat([(o["params"][n] - start[n]).reshape(-1) for n in want])
@@ -106,7 +106,10 @@ def test_two_rank_trainer_fit_equals_single_process(tmp_path, precision):
         if precision == "fp32":
             assert worst < 0.02 * LR * steps, worst
         else:
-            assert off < 1e-3 and l2 < 0.05 and worst <= 2.01 * LR * steps, (off, l2, worst)
+            # (the NUMBER is a chaotic quantity: two equally valid roundings of the frozen text features — bit-identical between
+            # the one-process and the two-rank run, 1e-3 apart from each other — gave 2.5e-4 and 2.7e-3 with the same code
+            # otherwise; a lost rank or a wrong divisor moves EVERY element: off ~ 1, l2 ~ 0.3)
+            assert off < 5e-3 and l2 < 0.05 and worst <= 2.01 * LR * steps, (off, l2, worst)
         assert abs(o["train_loss"] - ref.logged("train_loss")) < (1e-4 if precision == "fp32" else 2e-3) * abs(ref.logged("train_loss"))
         # hooks only on the boundary micro-batch, every gradient of the hooked tower produced in its bucket slice
         assert o["stats"]["grad_tensors_copied_per_step"] == 0 and o["stats"]["grad_tensors_written_in_place_per_step"] >= 30, o["stats"]
