@@ -110,7 +110,12 @@ def test_two_rank_trainer_fit_equals_single_process(tmp_path, precision):
             # the one-process and the two-rank run, 1e-3 apart from each other — gave 2.5e-4 and 2.7e-3 with the same code
             # otherwise; a lost rank or a wrong divisor moves EVERY element: off ~ 1, l2 ~ 0.3)
             assert off < 5e-3 and l2 < 0.05 and worst <= 2.01 * LR * steps, (off, l2, worst)
-        assert abs(o["train_loss"] - ref.logged("train_loss")) < (1e-4 if precision == "fp32" else 2e-3) * abs(ref.logged("train_loss"))
+        # bf16: 4 captions x 16 tokens per rank against 8 x 16 in one process put the frozen text tower's GEMMs on different
+        # kernels of the bf16 family (fp32 sums 1e-7 apart), and every bf16-rounded activation (q | k | v of each layer, the last
+        # one included since the one-row attention kernel) can turn such a difference into 2^-9: the loss after three updates
+        # then differs by up to ~2.5e-3.  At the sizes the step runs at, one kernel serves every M and the text features are
+        # bit-identical between batch splits.
+        assert abs(o["train_loss"] - ref.logged("train_loss")) < (1e-4 if precision == "fp32" else 5e-3) * abs(ref.logged("train_loss"))
         # hooks only on the boundary micro-batch, every gradient of the hooked tower produced in its bucket slice
         assert o["stats"]["grad_tensors_copied_per_step"] == 0 and o["stats"]["grad_tensors_written_in_place_per_step"] >= 30, o["stats"]
     for n in want:                                                   # the replicas never diverge
