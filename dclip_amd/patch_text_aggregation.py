@@ -404,12 +404,32 @@ class PatchTextAggregation(nn.Module):
         dev = self.device
         B, R = regions.shape[:2]
         with torch.no_grad():
+            # The two frozen towers share nothing until the tokens are packed: on the GPU the text tower is launched on a
+            # stream of its own (scratch lane 4) beside the region tower — its 19,712-row GEMMs have 154-616 tiles for 256
+            # CUs, the region tower's LayerNorm / attention launches leave the matrix pipes idle (DCLIP_TEACHER_TEXT_STREAM=0:
+            # one stream).  Not inside a HIP-graph capture (the fork would have to be part of every caller's warm-up).
+            import os
+            side = None
+            if regions.is_cuda and input_ids.is_cuda and not torch.cuda.is_current_stream_capturing() \
+                    and os.environ.get("DCLIP_TEACHER_TEXT_STREAM", "1") != "0":
+                if getattr(self, "_text_side_stream", None) is None:
+                    object.__setattr__(self, "_text_side_stream", torch.cuda.Stream(device=dev))
+                side = self._text_side_stream
+                here = torch.cuda.current_stream(dev)
+                side.wait_stream(here)
+                with torch.cuda.stream(side), ops.workspace_lane(4):
+                    sent, tokens, eos = self.text_tokenizer.token_level_ids(input_ids)
             emb = self.patch_tokenizer.encode_regions(regions.reshape(B * R, *regions.shape[2:])).view(B, R, -1)
             if region_counts is not None:
                 counts = region_counts.to(dev).to(torch.int32).contiguous()
                 rmax = max(int(region_counts.max()), 1)        # an image without boxes keeps ONE zero row (:489-491)
                 emb = ops.mask_rows(emb.contiguous(), counts)[:, :rmax].contiguous()
-            sent, tokens, eos = self.text_tokenizer.token_level_ids(input_ids)
+            if side is None:
+                sent, tokens, eos = self.text_tokenizer.token_level_ids(input_ids)
+            else:
+                here.wait_stream(side)
+                for t_ in (sent, tokens, eos):
+                    t_.record_stream(here)
             self.last_sentence_embedding = sent       # text_projection(final_LN(h)[first EOS]) of THIS call's captions
             if max_tokens is None:
                 max_tokens = max(int(eos.max()) - 1, 1)       # host sync; pass max_tokens to avoid it
