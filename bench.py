@@ -68,8 +68,8 @@ def step_flops_per_image(cfg, T) -> float:
 
 class single_stream:
     """Steps whose GEMM launches are bracketed by HIP events run every kernel ALONE on one stream: the second streams of the
-    step (the meta-teacher beside the student's forward, the weight-gradient GEMMs beside the data-gradient chain, the frozen
-    text tower) are switched off for them, so that a per-launch duration is that of the kernel, not of the kernel sharing the
+    step (the meta-teacher beside the student's forward and its text tower beside its region tower, the weight-gradient GEMMs
+    beside the data-gradient chain, the frozen text tower) are switched off for them, so that a per-launch duration is that of the kernel, not of the kernel sharing the
     chip with another stream's work.  `value` comes from steps with the second streams on."""
 
     def __init__(self, module, on: bool = True):
@@ -77,20 +77,26 @@ class single_stream:
 
     def __enter__(self):
         if self.on:
-            self.prev = (self.module.overlap_teacher, os.environ.get("DCLIP_BF16_WGRAD_STREAM"), self.module.overlap_frozen_text)
+            self.prev = (self.module.overlap_teacher, self.module.overlap_frozen_text,
+                         {k: os.environ.get(k) for k in self.ENV})
             self.module.overlap_teacher = False
             self.module.overlap_frozen_text = False
-            os.environ["DCLIP_BF16_WGRAD_STREAM"] = "0"
+            for k in self.ENV:
+                os.environ[k] = "0"
         return self
+
+    # second streams that are switched by environment variables read at call time (engine._SideWgrads, the meta-teacher's
+    # text tower beside its region tower)
+    ENV = ("DCLIP_BF16_WGRAD_STREAM", "DCLIP_TEACHER_TEXT_STREAM")
 
     def __exit__(self, *exc):
         if self.on:
-            self.module.overlap_teacher = self.prev[0]
-            self.module.overlap_frozen_text = self.prev[2]
-            if self.prev[1] is None:
-                os.environ.pop("DCLIP_BF16_WGRAD_STREAM", None)
-            else:
-                os.environ["DCLIP_BF16_WGRAD_STREAM"] = self.prev[1]
+            self.module.overlap_teacher, self.module.overlap_frozen_text = self.prev[0], self.prev[1]
+            for k, v in self.prev[2].items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
         return False
 
 
