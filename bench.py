@@ -100,6 +100,65 @@ class single_stream:
         return False
 
 
+class ClockSampler:
+    """Shader clock (MHz) and socket power (W) of THIS process's GPU, read from the hwmon files of its PCI function every
+    50 ms on a host thread while a region runs: the MFMA peaks of the roofline are quoted at 2.4 GHz, and at ~1.35 kW the card
+    does not hold that clock under these steps (profiles/r03_clocks_under_load.log).  Purely informative: every failure
+    (files absent or unreadable) leaves `summary()` at None."""
+    NOMINAL_MHZ = 2400.0
+
+    def __init__(self, device_index: int):
+        import glob
+        self.freq = self.power = None
+        self.samples = []
+        try:
+            pr = torch.cuda.get_device_properties(device_index)
+            addr = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+            for h in glob.glob(f"/sys/bus/pci/devices/{addr}/hwmon/hwmon*"):
+                if os.path.exists(os.path.join(h, "freq1_input")):
+                    self.freq = os.path.join(h, "freq1_input")
+                    self.power = os.path.join(h, "power1_input") if os.path.exists(os.path.join(h, "power1_input")) else None
+        except Exception:
+            self.freq = None
+        self._stop = None
+        self._thread = None
+
+    def _run(self):
+        while not self._stop.is_set():
+            try:
+                mhz = int(open(self.freq).read()) / 1e6
+                w = int(open(self.power).read()) / 1e6 if self.power else None
+                self.samples.append((mhz, w))
+            except Exception:
+                pass
+            self._stop.wait(0.05)
+
+    def __enter__(self):
+        if self.freq:
+            import threading
+            self._stop = threading.Event()
+            self._thread = threading.Thread(target=self._run, daemon=True)
+            self._thread.start()
+        return self
+
+    def __exit__(self, *exc):
+        if self._thread is not None:
+            self._stop.set()
+            self._thread.join(timeout=1.0)
+            self._thread = None
+        return False
+
+    def summary(self):
+        good = sorted(m for m, _ in self.samples if m > 0)
+        if len(good) < 3:
+            return None
+        good = good[len(good) // 4:]                 # the region starts from an idle card: drop the ramp
+        pw = sorted(w for _, w in self.samples if w)
+        return {"sclk_mhz": round(good[len(good) // 2], 0), "power_w": round(pw[len(pw) // 2], 0) if pw else None,
+                "samples": len(self.samples), "nominal_mhz": self.NOMINAL_MHZ,
+                "source": "hwmon freq1_input / power1_input of the device's PCI function, every 50 ms during the timed region"}
+
+
 class GemmTimer:
     """HIP events around every dclip_gemm_f32 launch, on the stream the kernels are launched on (torch's current
     stream — torch.cuda.Event records there).  Sum(flops) / Sum(elapsed) over the timed region is the roofline
@@ -311,10 +370,12 @@ def extra_config(dev, timer, which: str, steps: int, warmup: int):
         one(prefetch_ok and k_ + 1 < warmup)
     timer.enabled = False
     torch.cuda.synchronize()
+    clock = ClockSampler(dev.index if dev.index is not None else 0)
     t0 = time.perf_counter()
-    for k_ in range(steps):
-        last = one(prefetch_ok and k_ + 1 < steps)      # exactly K teacher passes inside the K timed steps
-    torch.cuda.synchronize()
+    with clock:
+        for k_ in range(steps):
+            last = one(prefetch_ok and k_ + 1 < steps)      # exactly K teacher passes inside the K timed steps
+        torch.cuda.synchronize()
     el = time.perf_counter() - t0
     ev_steps = 2 if which != "c5" else 1
     timer.records16.clear()
@@ -331,6 +392,9 @@ def extra_config(dev, timer, which: str, steps: int, warmup: int):
                               "events around every GEMM launch",
            "value": round(B * steps / el, 2), "unit": "images/s", "ms_per_step": round(ms, 3), "steps": steps, "warmup": warmup,
            "dtype": dtype, "loss": float(last)}
+    ck = clock.summary()
+    if ck is not None:
+        out["clock"] = ck
     if dtype == "bf16":
         f16, ms16, n16 = timer.summary(bf16=True)
         floor_ms = (student_flops + meta_teacher_flops(cfg, tcfg, B, R, T)) / 2500.0 / 1e9
@@ -628,7 +692,9 @@ def main():
         note(f"timed step {sampled['i'] - 1} launched")
         return out_
 
-    elapsed, last = timed(args.steps, timed_step)      # ---- THE timed region: exactly K steps
+    clock = ClockSampler(dev.index if dev.index is not None else 0)
+    with clock:
+        elapsed, last = timed(args.steps, timed_step)      # ---- THE timed region: exactly K steps
     timer.enabled = False
     n_sampled = max(1, sampled["n"])
     last_loss = float(last.detach())
@@ -775,6 +841,12 @@ def main():
                               "flops_per_image": step_flops_per_image(cfg, T)},
         }
         line.update(extra)
+        ck = clock.summary()
+        if ck is not None:
+            # context for the rooflines: the same fractions against the peak at the clock the card actually ran at
+            line["clock"] = ck
+            if line["roofline"]["frac"] is not None:
+                line["roofline"]["frac_at_measured_clock"] = round(line["roofline"]["frac"] * ck["nominal_mhz"] / ck["sclk_mhz"], 4)
         g16 = timer.summary(bf16=True) if not args.no_gemm_events else (0.0, 0.0, 0)
         if g16[2] and graphed is None:
             # bf16 GEMM family (frozen teacher towers, bf16 student): its own roofline against the dense bf16 MFMA peak
@@ -790,6 +862,8 @@ def main():
                                      "launches_per_step": g16[2] // n_ev,
                                      "gemm_ms_per_step": round(g16[1] / n_ev, 3),
                                      "gemm_flops_per_step": g16[0] / n_ev}
+            if ck is not None:
+                line["roofline_bf16"]["frac_at_measured_clock"] = round(line["roofline_bf16"]["frac"] * ck["nominal_mhz"] / ck["sclk_mhz"], 4)
         if args.student_precision == "bf16" and args.workload == "c2":
             line["config"]["workload"] = line["config"]["workload"].replace(
                 "fp32, vision", "STUDENT VISION TOWER IN bf16 (not the benched precision), vision")

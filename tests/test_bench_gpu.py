@@ -30,6 +30,8 @@ def test_bench_prints_one_json_line_with_roofline_and_cpu_baseline():
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["value"] > 0 and c["cores"] >= 1 and "sample" in c
     assert "workload" in d["config"] and "model" not in d["config"]
+    if "clock" in d:                 # informative (hwmon of the device, when readable): the clock the roofline's 2.4 GHz got
+        assert 90 <= d["clock"]["sclk_mhz"] <= 2600 and abs(r["frac_at_measured_clock"] * d["clock"]["sclk_mhz"] - r["frac"] * 2400.0) < 5.0
 
 
 def test_bare_gpus_2_self_launches_its_ranks():
