@@ -356,10 +356,12 @@ def vision_fwd_bf16(p: VisionParams, pixel_values: torch.Tensor, cfg, cache: dic
 # The student's vision tower with bf16 GEMM inputs in forward, dgrad AND wgrad (BASELINE configs c3 / c5 quote the step
 # in bf16; opt-in `precision="bf16"` with gradients enabled).  fp32 master weights (bf16 copies W and W^T are rebuilt
 # when the optimizer has stepped), fp32 accumulation, fp32 residual stream / LayerNorm statistics / softmax; the
-# attention core itself runs on the fp32 kernels (2 % of the FLOPs, HBM-bound).  The weight-gradient product
-# dW[out,in] = dY^T X is computed by the same C = A W^T kernel on token-contiguous operands (dY^T, X^T) written by
-# ops.transpose_bf16.  The patch embedding, the pooled LayerNorm and the projection stay fp32; every encoder layer is
-# run at full size (the CLS-row pruning of the fp32 schedule would keep a full-size fp32 qkv projection).
+# attention core runs on the bf16 MFMAs for sequences up to 64 tokens (attention_bf16.hip; the fp32 kernels above that).
+# The weight-gradient product dW[out,in] = dY^T X comes from the token-major split-K kernel on the operands as the backward
+# has them (for shapes it declines: the C = A W^T kernel on dY^T, X^T written by ops.transpose_bf16).  The patch embedding is
+# a bf16 GEMM pair too where that kernel takes its shape (_patch_embed_bf16); the pooled LayerNorm and the projection stay
+# fp32; every encoder layer is run at full size (the CLS-row pruning of the fp32 schedule would keep a full-size fp32 qkv
+# projection).
 
 def _w16t(cache: dict, key: str, w: torch.Tensor) -> torch.Tensor:
     """bf16 W^T [in, ld >= out] of an nn.Linear weight [out, in]: the `W` operand of the dgrad GEMM dX = dY (W^T)^T."""
