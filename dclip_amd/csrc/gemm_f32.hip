@@ -836,6 +836,18 @@ Plan make_plan(int M, int N, int K, int layout, int split_k) {
       return Plan{bm, bn, cdiv(K, kps), kps};
     }
   }
+  // Measured plans for the benched step's weight-gradient shapes (ViT-B width, 12,800 tokens: tools/gemm_wgrad_split_sweep.py,
+  // every tile x split count 2..24 on one box): the cost model below only tries power-of-two splits, and for these the best
+  // work-item count sits just under a whole number per CU with a split of 7 (144 x 7 = 1008 items = 3.94 per CU for 768 x 768;
+  // 432 x 7 = 3024 = 11.8 for 2304 x 768): 131.9 -> 119.4 us and 378.6 -> 345.3 us.  DCLIP_GEMM_PLAN_TABLE=0 switches it off.
+  if (split_k <= 0 && layout == 0 && K == 12800 && !(getenv("DCLIP_GEMM_PLAN_TABLE") && atoi(getenv("DCLIP_GEMM_PLAN_TABLE")) == 0)) {
+    int sp = 0;
+    if ((M == 2304 && N == 768) || (M == 768 && N == 768)) sp = 7;
+    if (sp) {
+      const int kps = cdiv(cdiv(K, sp), BK) * BK;
+      return Plan{64, 64, cdiv(K, kps), kps};
+    }
+  }
   const double mn_major_penalty = (layout & DCLIP_A_KMAJOR ? 0.0 : 0.03) + (layout & DCLIP_B_KMAJOR ? 0.0 : 0.03);
   double best = 1e300;
   Plan pl{128, 128, 1, K};
