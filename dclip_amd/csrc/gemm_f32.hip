@@ -836,17 +836,15 @@ Plan make_plan(int M, int N, int K, int layout, int split_k) {
       return Plan{bm, bn, cdiv(K, kps), kps};
     }
   }
-  // Measured plans for the benched step's weight-gradient shapes (ViT-B width, 12,800 tokens: tools/gemm_wgrad_split_sweep.py,
-  // every tile x split count 2..24 on one box): the cost model below only tries power-of-two splits, and for these the best
-  // work-item count sits just under a whole number per CU with a split of 7 (144 x 7 = 1008 items = 3.94 per CU for 768 x 768;
-  // 432 x 7 = 3024 = 11.8 for 2304 x 768): 131.9 -> 119.4 us and 378.6 -> 345.3 us.  DCLIP_GEMM_PLAN_TABLE=0 switches it off.
-  if (split_k <= 0 && layout == 0 && K == 12800 && !(getenv("DCLIP_GEMM_PLAN_TABLE") && atoi(getenv("DCLIP_GEMM_PLAN_TABLE")) == 0)) {
-    int sp = 0;
-    if ((M == 2304 && N == 768) || (M == 768 && N == 768)) sp = 7;
-    if (sp) {
-      const int kps = cdiv(cdiv(K, sp), BK) * BK;
-      return Plan{64, 64, cdiv(K, kps), kps};
-    }
+  // Measured plan for the out-projection's weight gradient of the benched step (768 x 768 x 12,800 tokens): the cost model
+  // below only tries power-of-two splits on its preferred tile; 64 x 64 tiles with 7 splits (144 x 7 = 1008 work items = 3.94
+  // per CU) measure 122-124 us against 130-131 on two boxes (tools/gemm_wgrad_split_sweep.py; profiles/r03_gemm_wgrad_split_sweep.log).
+  // The same sweep's 10 % for the qkv weight gradient did not reproduce on a second box (352-357 us either way) and is not
+  // encoded.  DCLIP_GEMM_PLAN_TABLE=0 switches the entry off.
+  if (split_k <= 0 && layout == 0 && K == 12800 && M == 768 && N == 768 &&
+      !(getenv("DCLIP_GEMM_PLAN_TABLE") && atoi(getenv("DCLIP_GEMM_PLAN_TABLE")) == 0)) {
+    const int kps = cdiv(cdiv(K, 7), BK) * BK;
+    return Plan{64, 64, cdiv(K, kps), kps};
   }
   const double mn_major_penalty = (layout & DCLIP_A_KMAJOR ? 0.0 : 0.03) + (layout & DCLIP_B_KMAJOR ? 0.0 : 0.03);
   double best = 1e300;
