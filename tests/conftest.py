@@ -27,7 +27,8 @@ def golden():
 # workers) run FIRST: behind the rest of the suite each of them took ~50 s instead of ~5 (the parent then holds a HIP context
 # with tens of GB of cached allocations and every code object of the suite; measured 567 s for the whole suite against ~200 s
 # this way), and a module's cached device memory is returned when the module is done.
-_MULTI_PROCESS_FIRST = ("test_dist_gpu.py", "test_entrypoints_dp_gpu.py", "test_training_gpu.py", "test_bench_gpu.py")
+_MULTI_PROCESS_FIRST = ("test_dist_gpu.py", "test_entrypoints_dp_gpu.py", "test_teacher_prefetch_gpu.py", "test_training_gpu.py",
+                        "test_bench_gpu.py")
 
 
 def pytest_collection_modifyitems(session, config, items):

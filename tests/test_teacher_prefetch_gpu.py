@@ -128,3 +128,47 @@ def test_trainer_with_and_without_the_pipelined_teacher_trains_the_same_weights(
     for n in want:
         assert torch.equal(got[n], want[n]), n
     assert sum(int(not torch.equal(want[n], start[n])) for n in want) > 10      # the run did train
+
+
+def _dp_worker(rank, world, port, prefetch_on, out):
+    import os
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0",
+                      DCLIP_TEACHER_PREFETCH="1" if prefetch_on else "0")
+    import torch.distributed as dist
+    from dclip_amd.lightning_lite import Trainer
+    mod, cfg = _module(seed=5)
+    batches = _batches(cfg, 2 * 4, device=mod.device)              # 4 batches per rank
+    calls = []
+    real = mod.prefetch_teacher
+    mod.prefetch_teacher = lambda b_: calls.append(real(b_)) or calls[-1]
+    tr = Trainer(max_epochs=1, gradient_clip_val=0.5, accumulate_grad_batches=2, devices=world, dist_backend="gloo", bucket_mb=0.05)
+    tr.fit(mod, batches)
+    torch.cuda.synchronize()
+    out[(prefetch_on, rank)] = dict(params={n: p.detach().float().cpu().clone() for n, p in mod.named_parameters() if p.requires_grad},
+                                    calls=list(calls), stats=tr.grad_sync.stats())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_with_the_pipelined_teacher_train_the_same_weights():
+    """Data parallel + pipelined teacher: two gloo ranks on the one GPU, each starting ITS next batch's teacher while the
+    all-reduce of the current gradients is launched from inside the backward — the trained weights equal those of the same
+    two ranks with the teacher run inside the step, bit for bit, and the replicas agree."""
+    import socket
+    import torch.multiprocessing as mp
+    res = {}
+    for on in (False, True):
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        out = mp.Manager().dict()
+        mp.spawn(_dp_worker, args=(2, port, on, out), nprocs=2, join=True)
+        res.update(dict(out))
+    for r in (0, 1):
+        assert res[(False, r)]["calls"] == [False] * 3 and res[(True, r)]["calls"] == [True] * 3       # 4 batches per rank
+        assert res[(True, r)]["stats"]["grad_tensors_copied_per_step"] == 0
+        for n, w in res[(False, r)]["params"].items():
+            assert torch.equal(res[(True, r)]["params"][n], w), (r, n)
+    for n, w in res[(True, 0)]["params"].items():
+        assert torch.equal(res[(True, 1)]["params"][n], w), n
